@@ -1,0 +1,178 @@
+"""ctypes binding of oracle/libpih_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (peg_in_hole_gym_amd) never does.  PARITY UNPINNED vs PyBullet (see pih_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+STATE_WORDS = 128
+CMAX = 64
+NDOF = 38
+
+
+class Config(C.Structure):
+    _fields_ = [("n_envs", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32), ("ik_iters", C.c_int32),
+                ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("enable_self_collision", C.c_int32),
+                ("reserved", C.c_int32), ("seed", C.c_uint64), ("dt", C.c_double), ("residual_threshold", C.c_double),
+                ("erp", C.c_double), ("warmstart", C.c_double), ("contact_margin", C.c_double), ("linear_slop", C.c_double),
+                ("ik_damping", C.c_double), ("ik_residual", C.c_double), ("dv", C.c_double)]
+
+
+def build(force=False):
+    """Compile the oracle with the committed Makefile (gcc only)."""
+    if force or not os.path.exists(os.path.join(_DIR, "libpih_oracle.so")) or not os.path.exists(os.path.join(_DIR, "libpih_oracle_omp.so")):
+        subprocess.check_call(["make", "-C", _DIR, "-s"] + (["-B"] if force else []))
+
+
+_libs = {}
+
+
+def lib(omp=False):
+    name = "libpih_oracle_omp.so" if omp else "libpih_oracle.so"
+    if name not in _libs:
+        path = os.path.join(_DIR, name)
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        dp = C.POINTER(C.c_double)
+        L.piho_create.restype = C.c_void_p
+        L.piho_create.argtypes = [C.POINTER(Config), dp]
+        L.piho_destroy.argtypes = [C.c_void_p]
+        L.piho_reset.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.piho_step.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_uint8)]
+        for f in ("piho_get_state", "piho_get_tip_pose", "piho_get_contact_force"):
+            getattr(L, f).argtypes = [C.c_void_p, dp]
+        L.piho_set_state.argtypes = [C.c_void_p, dp]
+        L.piho_get_ncontacts.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.piho_debug_contacts.argtypes = [C.c_void_p, C.c_int, dp]
+        L.piho_debug_contacts.restype = C.c_int
+        L.piho_debug_udot.argtypes = [C.c_void_p, C.c_int, dp]
+        L.piho_fsm_update.restype = C.c_int
+        _libs[name] = L
+    return _libs[name]
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def default_config(**kw):
+    c = Config()
+    lib().piho_default_config(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+class Oracle:
+    """N-env fp64 CPU simulator with the same step/reset/get_state surface as the HIP product."""
+
+    def __init__(self, n_envs=1, offsets=None, omp=False, **kw):
+        self.L = lib(omp)
+        self.cfg = default_config(n_envs=n_envs, **kw)
+        self.n = n_envs
+        off = None
+        if offsets is not None:
+            off = np.ascontiguousarray(offsets, dtype=np.float64).reshape(n_envs, 3)
+        self.h = self.L.piho_create(C.byref(self.cfg), _dp(off) if off is not None else None)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.piho_destroy(self.h)
+            self.h = None
+
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+        self.L.piho_reset(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None)
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n, 4)
+        obs = np.zeros((self.n, 5)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.uint8)
+        self.L.piho_step(self.h, _dp(a), _dp(obs), _dp(rew), done.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return obs, rew, done
+
+    def get_state(self):
+        s = np.zeros((self.n, STATE_WORDS)); self.L.piho_get_state(self.h, _dp(s)); return s
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64).reshape(self.n, STATE_WORDS); self.L.piho_set_state(self.h, _dp(s))
+
+    def tip_pose(self):
+        t = np.zeros((self.n, 7)); self.L.piho_get_tip_pose(self.h, _dp(t)); return t
+
+    def contact_force(self):
+        f = np.zeros(self.n); self.L.piho_get_contact_force(self.h, _dp(f)); return f
+
+    def ncontacts(self):
+        n = np.zeros(self.n, dtype=np.int32); self.L.piho_get_ncontacts(self.h, n.ctypes.data_as(C.POINTER(C.c_int32))); return n
+
+    def debug_contacts(self, env=0):
+        out = np.zeros((CMAX, 12)); k = self.L.piho_debug_contacts(self.h, env, _dp(out)); return out[:k]
+
+    def debug_udot(self, env=0):
+        out = np.zeros(NDOF); self.L.piho_debug_udot(self.h, env, _dp(out)); return out
+
+
+# ---- stand-alone primitives
+def fk_arm(q, link=9):
+    q = np.ascontiguousarray(q, dtype=np.float64); p = np.zeros(3); qt = np.zeros(4)
+    lib().piho_fk_arm(_dp(q), C.c_int(link), _dp(p), _dp(qt)); return p, qt
+
+
+def jacobian_ee(q):
+    q = np.ascontiguousarray(q, dtype=np.float64); Jl = np.zeros((3, 9)); Ja = np.zeros((3, 9))
+    lib().piho_jacobian_ee(_dp(q), _dp(Jl), _dp(Ja)); return Jl, Ja
+
+
+def ik(q0, tpos, tquat, cfg=None):
+    cfg = cfg or default_config()
+    q0 = np.ascontiguousarray(q0, dtype=np.float64); tp = np.ascontiguousarray(tpos, dtype=np.float64)
+    tq = np.ascontiguousarray(tquat, dtype=np.float64); out = np.zeros(9)
+    lib().piho_ik(C.byref(cfg), _dp(q0), _dp(tp), _dp(tq), _dp(out)); return out
+
+
+def mass_matrix(state):
+    s = np.ascontiguousarray(state, dtype=np.float64); M = np.zeros((NDOF, NDOF)); lib().piho_mass_matrix(_dp(s), _dp(M)); return M
+
+
+def free_accel(state, cfg=None):
+    cfg = cfg or default_config(); s = np.ascontiguousarray(state, dtype=np.float64); ud = np.zeros(NDOF)
+    lib().piho_free_accel(C.byref(cfg), _dp(s), _dp(ud)); return ud
+
+
+def vel_constraint(cur, tar, dv):
+    c = np.ascontiguousarray(cur, dtype=np.float64); t = np.ascontiguousarray(tar, dtype=np.float64); o = np.zeros(3)
+    lib().piho_vel_constraint(_dp(c), _dp(t), C.c_double(dv), _dp(o)); return o
+
+
+def rotate_vector(v, q):
+    v = np.ascontiguousarray(v, dtype=np.float64); q = np.ascontiguousarray(q, dtype=np.float64); o = np.zeros(3)
+    lib().piho_rotate_vector(_dp(v), _dp(q), _dp(o)); return o
+
+
+def quat_from_euler(rpy):
+    r = np.ascontiguousarray(rpy, dtype=np.float64); q = np.zeros(4); lib().piho_quat_from_euler(_dp(r), _dp(q)); return q
+
+
+def euler_from_quat(q):
+    q = np.ascontiguousarray(q, dtype=np.float64); r = np.zeros(3); lib().piho_euler_from_quat(_dp(q), _dp(r)); return r
+
+
+def fsm_trace(n_steps, dt=1.0 / 240):
+    st = C.c_double(0); t = C.c_double(0); out = []
+    for _ in range(n_steps):
+        out.append(lib().piho_fsm_update(C.byref(st), C.byref(t), C.c_double(dt)))
+    return out
+
+
+def env_offsets(offset, n):
+    o = np.ascontiguousarray(offset, dtype=np.float64); out = np.zeros((n, 3))
+    lib().piho_env_offsets(_dp(o), C.c_int(n), _dp(out)); return out

@@ -1,0 +1,88 @@
+/* pih_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * fp64, scalar, plain-C restatement of the per-env physics the reference delegates to PyBullet
+ *  plus the reference's own Python controller glue
+ * (envs/utils.py:60-95, envs/peg_in_hole.py:206-225).  It is the checker for the HIP product in
+ * peg_in_hole_gym_amd/csrc; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it.  The product never links, imports or falls back to anything in oracle/.
+ *
+ * PARITY UNPINNED against PyBullet: pybullet / pybullet_data are not installable in this pipeline and
+ * the reference has no tests or golden trajectories.  The oracle is pinned by
+ *   (1) golden vectors of the reference's pure-Python glue (tests/golden/glue_golden.json), and
+ *   (2) analytic known-answer tests (tests/test_oracle_kat.py): Franka DH closed form, Jacobian vs
+ *       finite differences, free fall closed form, resting normal force = m g, Coulomb cone, ...
+ */
+#ifndef PIH_ORACLE_H
+#define PIH_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIHO_STATE_WORDS 128
+#define PIHO_CMAX 64          /* max simultaneous contacts per env */
+#define PIHO_NDOF 38
+
+/* state record word offsets (identical to the product's float record, include/pih.h) */
+enum {
+  PIHO_S_QARM = 0, PIHO_S_QDARM = 9, PIHO_S_POS = 18, PIHO_S_QUAT = 21, PIHO_S_VLIN = 25, PIHO_S_VANG = 28,
+  PIHO_S_QJ = 31, PIHO_S_QDJ = 54, PIHO_S_TARGET = 77,
+  PIHO_S_FSM = 86, PIHO_S_FSMT = 87, PIHO_S_DONE = 88, PIHO_S_GRASP = 89, PIHO_S_RANDY = 90, PIHO_S_ATTACH = 91,
+  PIHO_S_RNG = 92, PIHO_S_STEPS = 93, PIHO_S_OFFSET = 94, PIHO_S_SPARE = 97
+};
+
+typedef struct {
+  int32_t n_envs;
+  int32_t mode;               /* 0 = action mode (envs/utils.py:60-68), 1 = scripted episode (envs/peg_in_hole.py:53-112) */
+  int32_t solver_iters;       /* 50 */
+  int32_t ik_iters;           /* 20 */
+  int32_t max_episode_steps;  /* action mode: done after this many steps */
+  int32_t auto_reset;         /* 1: envs that finish are reset inside step() */
+  int32_t enable_self_collision;
+  int32_t reserved;
+  uint64_t seed;
+  double dt;                  /* 1/240 */
+  double residual_threshold;  /* 1e-7 (squared velocity residual), 0 = never exit early */
+  double erp;                 /* 0.2 */
+  double warmstart;           /* 0.85 */
+  double contact_margin;      /* 0.005 */
+  double linear_slop;         /* 1e-5 */
+  double ik_damping;          /* 0.5 */
+  double ik_residual;         /* 1e-4 */
+  double dv;                  /* per-step EE clamp: 2/240 action mode (envs/utils.py:60), 0.05 scripted (envs/peg_in_hole.py:259) */
+} piho_config;
+
+typedef struct piho_handle piho_handle;
+
+void piho_default_config(piho_config* c);
+piho_handle* piho_create(const piho_config* c, const double* offsets /* [n,3] or NULL */);
+void piho_destroy(piho_handle* h);
+void piho_reset(piho_handle* h, const uint8_t* mask /* [n] or NULL = all */);
+/* actions [n,4]; obs [n,5]; reward [n]; done [n] */
+void piho_step(piho_handle* h, const double* actions, double* obs, double* reward, uint8_t* done);
+void piho_get_state(const piho_handle* h, double* out /* [n,128] */);
+void piho_set_state(piho_handle* h, const double* in /* [n,128] */);   /* also clears the warm-start cache */
+void piho_get_tip_pose(const piho_handle* h, double* out /* [n,7] */);
+void piho_get_contact_force(const piho_handle* h, double* out /* [n] sum of normal impulses / dt of the last step */);
+void piho_get_ncontacts(const piho_handle* h, int32_t* out /* [n] */);
+
+/* stand-alone primitives (KATs and stage-wise GPU bring-up) */
+void piho_fk_arm(const double q[9], int link /* 0..8, or 9 = EE */, double pos[3], double quat[4]);
+void piho_jacobian_ee(const double q[9], double Jlin[27], double Jang[27]);     /* row-major 3x9 each */
+void piho_ik(const piho_config* c, const double q0[9], const double tpos[3], const double tquat[4], double qout[9]);
+void piho_mass_matrix(const double state[128], double M[38 * 38]);
+void piho_free_accel(const piho_config* c, const double state[128], double udot[38]);
+void piho_vel_constraint(const double cur[3], const double tar[3], double dv, double out[3]);
+void piho_rotate_vector(const double v[3], const double q[4], double out[3]);
+void piho_quat_from_euler(const double rpy[3], double q[4]);
+void piho_euler_from_quat(const double q[4], double rpy[3]);
+int piho_fsm_update(double* state, double* t, double dt);   /* envs/peg_in_hole.py:206-212 */
+void piho_env_offsets(const double offset[3], int n, double* out /* [n,3] */);   /* envs/base_env.py:35-55 */
+/* debug: contact list + solver rows of env 0 from the last step */
+int piho_debug_contacts(const piho_handle* h, int env, double* out /* [CMAX,12]: linkA linkB px py pz nx ny nz depth mu key lambda_n */);
+void piho_debug_udot(const piho_handle* h, int env, double* out /* [38] free acceleration of the last step */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
