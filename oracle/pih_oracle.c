@@ -15,7 +15,7 @@
  * Dynamics algorithm (deliberately different from the product's ABA so the parity test compares two
  * independent derivations): world-frame recursive Newton-Euler (RNEA) gives the bias force and, column by
  * column, the joint-space mass matrix; dense Cholesky gives M^-1; constraint rows are solved with Bullet's
- * sequential-impulse PGS in velocity space.
+ * sequential-impulse PGS in velocity space (row order: motors, joint limits, then per contact normal/dir1/dir2).
  */
 #include "pih_oracle.h"
 #include "../include/pih_model.h"
@@ -713,32 +713,30 @@ static void step_env(piho_handle* h, int e, const double* action, double* obs, d
     }
   }
   int row_n0 = nr, nc = E->ncontacts;
-  for (int pass = 0; pass < 2; pass++)   /* all normals first, then (dir1, dir2) per contact */
-    for (int i = 0; i < nc; i++) {
-      const Contact* ct = &E->contacts[i];
-      v3 t1, t2; plane_space(ct->n, t1, t2);
-      int reps = pass == 0 ? 1 : 2;
-      for (int rep = 0; rep < reps; rep++) {
-        const double* dir = pass == 0 ? ct->n : (rep == 0 ? t1 : t2);
-        Row* r = &rows[nr++];
-        memset(r, 0, sizeof *r);
-        jac_row(K, ct->linkA, ct->p, dir, 1.0, r->J);
-        if (ct->linkB >= 0) jac_row(K, ct->linkB, ct->p, dir, -1.0, r->J);
-        memcpy(r->W, r->J, sizeof r->J); minv_apply(M, r->W);
-        double jw = 0, ju = 0; for (int k = 0; k < ND; k++) { jw += r->J[k] * r->W[k]; ju += r->J[k] * u[k]; }
-        r->dinv = 1.0 / jw;
-        if (pass == 0) {
-          double pen = ct->depth + c->linear_slop;
-          double vb = pen > 0 ? -pen / dt : -c->erp * pen / dt;
-          r->rhs = (vb - ju) * r->dinv; r->lo = 0; r->hi = 1e30; r->fparent = -1;
-          for (int k = 0; k < E->ncache; k++) if (E->cache_key[k] == ct->key) { r->lambda = c->warmstart * E->cache_lambda[k]; break; }
-        } else { r->rhs = -ju * r->dinv; r->fparent = row_n0 + i; r->mu = ct->mu; }
-      }
+  for (int i = 0; i < nc; i++) {          /* per contact: normal, friction dir 1, friction dir 2 (interleaved order) */
+    const Contact* ct = &E->contacts[i];
+    v3 t1, t2; plane_space(ct->n, t1, t2);
+    for (int rep = 0; rep < 3; rep++) {
+      const double* dir = rep == 0 ? ct->n : (rep == 1 ? t1 : t2);
+      Row* r = &rows[nr++];
+      memset(r, 0, sizeof *r);
+      jac_row(K, ct->linkA, ct->p, dir, 1.0, r->J);
+      if (ct->linkB >= 0) jac_row(K, ct->linkB, ct->p, dir, -1.0, r->J);
+      memcpy(r->W, r->J, sizeof r->J); minv_apply(M, r->W);
+      double jw = 0, ju = 0; for (int k = 0; k < ND; k++) { jw += r->J[k] * r->W[k]; ju += r->J[k] * u[k]; }
+      r->dinv = 1.0 / jw;
+      if (rep == 0) {
+        double pen = ct->depth + c->linear_slop;
+        double vb = pen > 0 ? -pen / dt : -c->erp * pen / dt;
+        r->rhs = (vb - ju) * r->dinv; r->lo = 0; r->hi = 1e30; r->fparent = -1;
+        for (int k = 0; k < E->ncache; k++) if (E->cache_key[k] == ct->key) { r->lambda = c->warmstart * E->cache_lambda[k]; break; }
+      } else { r->rhs = -ju * r->dinv; r->fparent = row_n0 + 3 * i; r->mu = ct->mu; }
     }
+  }
 
   /* ---- sequential impulse (Bullet resolveSingleConstraintRowGeneric form) */
   double dv[ND]; memset(dv, 0, sizeof dv);
-  for (int i = row_n0; i < row_n0 + nc; i++) if (rows[i].lambda != 0) for (int k = 0; k < ND; k++) dv[k] += rows[i].W[k] * rows[i].lambda;
+  for (int i = 0; i < nc; i++) { const Row* r = &rows[row_n0 + 3 * i]; if (r->lambda != 0) for (int k = 0; k < ND; k++) dv[k] += r->W[k] * r->lambda; }
   for (int it = 0; it < c->solver_iters; it++) {
     double res2 = 0;
     for (int i = 0; i < nr; i++) {
@@ -763,8 +761,8 @@ static void step_env(piho_handle* h, int e, const double* action, double* obs, d
   /* warm-start cache + contact normal force (p11) */
   E->ncache = nc; E->contact_force = 0;
   for (int i = 0; i < nc; i++) {
-    E->cache_key[i] = E->contacts[i].key; E->cache_lambda[i] = rows[row_n0 + i].lambda; E->lambda_n[i] = rows[row_n0 + i].lambda;
-    if (E->contacts[i].key < 1000) E->contact_force += rows[row_n0 + i].lambda / dt;
+    E->cache_key[i] = E->contacts[i].key; E->cache_lambda[i] = rows[row_n0 + 3 * i].lambda; E->lambda_n[i] = rows[row_n0 + 3 * i].lambda;
+    if (E->contacts[i].key < 1000) E->contact_force += rows[row_n0 + 3 * i].lambda / dt;
   }
 
   /* ---- integrate positions (semi-implicit Euler; base orientation by the exponential map) */
