@@ -1,0 +1,104 @@
+/* pih.h -- C ABI of the MI355X-native vectorised peg-in-hole environment (libpih_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of guodashun/peg-in-hole-gym: the per-env PyBullet calls the
+ * reference makes from BaseEnv.step / PegInHole.* (paths relative to /root/reference/peg_in_hole_gym/):
+ *
+ *   pih_step      replaces  envs/base_env.py:60-75 (apply_action + stepSimulation + get_info for every agent), i.e.
+ *                           p.stepSimulation (envs/base_env.py:64, envs/peg_in_hole.py:108),
+ *                           p.calculateInverseKinematics + p.setJointMotorControlArray via panda_execute
+ *                           (envs/utils.py:60-68), p.getLinkState (envs/utils.py:62, envs/peg_in_hole.py:58,115,123)
+ *                           and the Python multiprocessing scatter/gather of envs/base_env_mp.py:40-51,75-87
+ *   pih_reset     replaces  envs/base_env.py:84-94 + envs/peg_in_hole.py:227-274 (loadURDF/resetJointState scene build)
+ *   pih_ik        replaces  p.calculateInverseKinematics stand-alone (envs/utils.py:67,79; envs/meta_env.py:92,104)
+ *   pih_get_state replaces  p.getLinkState / p.getJointState / (north_star) getContactPoints normal force read-backs
+ *
+ * Conventions: every call returns 0 on success, <0 on error (pih_last_error gives the text).  All *_dev pointers
+ * are DEVICE pointers owned by the caller (PyTorch-ROCm tensors); the library borrows them for the call and owns
+ * only its internal per-env state.  Work is enqueued on the caller's HIP stream (`stream` = hipStream_t, 0 =
+ * default stream) and is asynchronous.  One handle per device; a handle is not thread-safe; handles are independent.
+ * There is NO CPU fallback: creation fails if no HIP device is present.
+ */
+#ifndef PIH_H
+#define PIH_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIH_ABI_VERSION 1
+#define PIH_STATE_WORDS 256   /* float words per env record: [0,128) physical state, [128,256) warm-start contact cache */
+#define PIH_ACTION_DIM 4      /* envs/peg_in_hole.py:12 */
+#define PIH_OBS_DIM 5         /* envs/peg_in_hole.py:13: finger1, finger2, ee x, y, z */
+#define PIH_DEBUG_WORDS 1024
+
+/* state record word offsets (float32) */
+enum {
+  PIH_S_QARM = 0, PIH_S_QDARM = 9, PIH_S_POS = 18, PIH_S_QUAT = 21, PIH_S_VLIN = 25, PIH_S_VANG = 28,
+  PIH_S_QJ = 31, PIH_S_QDJ = 54, PIH_S_TARGET = 77,
+  PIH_S_FSM = 86, PIH_S_FSMT = 87, PIH_S_DONE = 88, PIH_S_GRASP = 89, PIH_S_RANDY = 90, PIH_S_ATTACH = 91,
+  PIH_S_RNG = 92, PIH_S_STEPS = 93, PIH_S_OFFSET = 94, PIH_S_SPARE = 97,
+  PIH_S_TIP = 98,          /* peg-tip pose xyz + quat(xyzw) after the last step (7) */
+  PIH_S_CFORCE = 105,      /* sum of contact normal impulses / dt of the last step [N] */
+  PIH_S_NCONTACT = 106,
+  PIH_S_PGS_ITERS = 107,   /* PGS iterations actually executed in the last step */
+  PIH_S_CACHE_N = 128, PIH_S_CACHE_KEY = 129, PIH_S_CACHE_LAMBDA = 129 + 48
+};
+
+/* pih_get_state / pih_set_state fields */
+enum {
+  PIH_FIELD_STATE = 0,         /* float[n, PIH_STATE_WORDS] */
+  PIH_FIELD_TIP_POSE = 1,      /* float[n, 7]  (get only)  envs/peg_in_hole.py:58,115 */
+  PIH_FIELD_CONTACT_FORCE = 2, /* float[n]     (get only)  north_star contact-normal force */
+  PIH_FIELD_DEBUG = 3          /* float[n, PIH_DEBUG_WORDS] (get only; filled when config.debug != 0) */
+};
+
+typedef struct pih_config {
+  int32_t n_envs;             /* envs on THIS device (mp_num * sub_num / world_size) */
+  int32_t env_index0;         /* global index of this device's first env (block partition; seeds = seed+1000+global index) */
+  int32_t mode;               /* 0 = action mode (panda_execute, envs/utils.py:60-68); 1 = scripted episode (envs/peg_in_hole.py:53-112) */
+  int32_t solver_iters;       /* 50 */
+  int32_t ik_iters;           /* 20 */
+  int32_t max_episode_steps;  /* action mode: done after this many steps (2227) */
+  int32_t auto_reset;         /* 1: finished envs are reset inside pih_step */
+  int32_t enable_self_collision;
+  int32_t debug;              /* 1: fill the debug buffer each step */
+  int32_t reserved;
+  uint64_t seed;
+  float dt;                   /* 1/240 */
+  float residual_threshold;   /* 1e-7 */
+  float erp;                  /* 0.2 */
+  float warmstart;            /* 0.85 */
+  float contact_margin;       /* 0.005 */
+  float linear_slop;          /* 1e-5 */
+  float ik_damping;           /* 0.5 */
+  float ik_residual;          /* 1e-4 */
+  float dv;                   /* 2/240 (action mode) or 0.05 (scripted) */
+  float reserved_f[3];
+} pih_config;
+
+typedef struct pih_handle pih_handle;
+
+void pih_default_config(pih_config* cfg);
+int pih_abi_version(void);
+/* offsets_host: HOST float[n_envs,3] (envs/base_env.py:35-55 placement) or NULL for zeros */
+int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** out);
+int pih_destroy(pih_handle* h);
+/* mask_dev: uint8[n] (nonzero = reset that env) or NULL = all.  hard is accepted for API parity (envs/base_env.py:85) */
+int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, void* stream);
+/* actions_dev float[n,4]; obs_dev float[n,5]; reward_dev float[n]; done_dev uint8[n] */
+int pih_step(pih_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+/* k consecutive steps with the same action buffer (scripted mode ignores actions: may be NULL) in one call */
+int pih_step_n(pih_handle* h, int k, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+int pih_get_state(pih_handle* h, int field, void* out_dev, void* stream);
+int pih_set_state(pih_handle* h, int field, const void* in_dev, void* stream);
+/* stand-alone batched IK: q0 float[n,9], tpos float[n,3], tquat float[n,4] (xyzw) -> qout float[n,9] */
+int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream);
+/* kernel timing with HIP events on `stream`: average ms per pih_step launch since the last call with reset=1 */
+int pih_timing(pih_handle* h, int reset, double* avg_ms_out, int64_t* launches_out);
+int pih_set_timing(pih_handle* h, int enable);
+const char* pih_last_error(pih_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

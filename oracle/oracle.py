@@ -10,7 +10,7 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 STATE_WORDS = 128
-CMAX = 64
+CMAX = 48
 NDOF = 38
 
 

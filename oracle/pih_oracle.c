@@ -545,7 +545,8 @@ static void collide(const piho_config* c, Env* E, const LinkKin* K) {
     int L = ANL + SAMP_LINK[i];
     add_contact(E, L, -1, 100 + i, p, n, depth, L_MU[L] * PIH_HOLE_MU);
   }
-  /* finger pad boxes */
+  /* finger pad boxes; at most PIHO_CAMAX contacts may involve the arm */
+  int nca = 0;
   for (int f = 0; f < 2; f++) {
     const LinkKin* kf = &K[PIH_FINGER_LINK0 + f];
     v3 bc; m_mulv(bc, kf->R, FBOX_C[f]); v_add(bc, bc, kf->o);
@@ -568,7 +569,8 @@ static void collide(const piho_config* c, Env* E, const LinkKin* K) {
       v3 n, p; m_mulv(n, kf->R, nl);
       v_cp(p, sp[i]); v_axpy(p, -(r + 0.5 * depth), n);
       int L = ANL + SAMP_LINK[i];
-      add_contact(E, L, PIH_FINGER_LINK0 + f, 300 + f * PIH_PIPE_NSAMP + i, p, n, depth, L_MU[L] * L_MU[PIH_FINGER_LINK0 + f]);
+      if (nca >= PIHO_CAMAX) continue;
+      nca += add_contact(E, L, PIH_FINGER_LINK0 + f, 300 + f * PIH_PIPE_NSAMP + i, p, n, depth, L_MU[L] * L_MU[PIH_FINGER_LINK0 + f]);
     }
   }
   /* pipe self collision (URDF_USE_SELF_COLLISION, envs/peg_in_hole.py:242): capsule segments s<t, non adjacent */

@@ -20,7 +20,8 @@ extern "C" {
 #endif
 
 #define PIHO_STATE_WORDS 128
-#define PIHO_CMAX 64          /* max simultaneous contacts per env */
+#define PIHO_CMAX 48          /* max simultaneous contacts per env (same caps as the product) */
+#define PIHO_CAMAX 12         /* of which may involve the arm */
 #define PIHO_NDOF 38
 
 /* state record word offsets (identical to the product's float record, include/pih.h) */

@@ -1,0 +1,1036 @@
+// pih_device.h -- the per-env step of the MI355X-native peg-in-hole environment: ONE WAVEFRONT PER ENV.
+//
+// Structure: a sequence of phases.  `w.par(n, f)` runs f(i) for i in [0,n) with lane = i mod 64 (lane-parallel
+// work: links, collision samples, constraint rows, DOFs); code outside par regions is wave-uniform (every lane
+// computes the same scalars; used for the short serial recursions down the kinematic chains).  All inter-phase data
+// lives in `Shared` (LDS on the GPU).  The same source compiles for the host (PIH_HOST_EMUL) ONLY for the test
+// harness in tests/emul, which lets the algorithm be checked against the fp64 oracle without a GPU; the product
+// (libpih_hip.so) contains the device build only and has no CPU path.
+//
+// What replaces what (paths relative to /root/reference/peg_in_hole_gym/):
+//   fk_*            p.getLinkState                    envs/utils.py:62, envs/peg_in_hole.py:58,115,123
+//   ik_solve        p.calculateInverseKinematics      envs/utils.py:67 (BussIK DLS restated)
+//   controller      panda_execute / grasp_process     envs/utils.py:60-68 / envs/peg_in_hole.py:122-212
+//   collide, aba, build_rows, pgs, integrate   p.stepSimulation   envs/base_env.py:64, envs/peg_in_hole.py:108
+//   reset_env       PegInHole.reset                   envs/peg_in_hole.py:227-274
+//
+// Dynamics: articulated-body algorithm in world-aligned axes with each link's own origin as reference point
+// (parent<->child transforms are pure translations; classical accelerations, so the floating base comes out directly
+// in the (world linear velocity of the base origin, world angular velocity) parameterisation the state uses).
+// Constraint rows get their unit-impulse response from the same articulated inertias (one lane per row), then
+// sequential-impulse PGS runs with one lane per DOF; the Jacobian entries are recomputed on the fly from the
+// contact point/direction so only the response rows (W = M^-1 J^T) are staged in LDS.
+#pragma once
+#include "../../include/pih.h"
+#include "../../include/pih_model.h"
+#include "pih_math.h"
+
+namespace pih {
+
+constexpr int NL = PIH_NL, ANL = PIH_ARM_NL, ONL = PIH_OBJ_NL, ND = PIH_NDOF;
+constexpr int NSAMP = PIH_PIPE_NSAMP;
+constexpr int CMAX = 48;      // contacts per env
+constexpr int CAMAX = 12;     // of which may involve the arm
+constexpr int NROWC = 3 * CMAX;
+constexpr int WPS = 31;       // LDS row stride of the pipe response rows (29 used, odd => conflict free)
+constexpr int NMOT = 32;      // 9 arm + 23 pipe joint motors
+constexpr int NLIM = 18;
+
+PIH_CONST int L_PARENT[NL] = PIH_LINK_PARENT;
+PIH_CONST int L_JTYPE[NL] = PIH_LINK_JTYPE;
+PIH_CONST real L_RFIX[NL][9] = PIH_LINK_RFIX;
+PIH_CONST real L_TFIX[NL][3] = PIH_LINK_TFIX;
+PIH_CONST real L_AXIS[NL][3] = PIH_LINK_AXIS;
+PIH_CONST real L_MASS[NL] = PIH_LINK_MASS;
+PIH_CONST real L_COM[NL][3] = PIH_LINK_COM;
+PIH_CONST real L_INERTIA[NL][6] = PIH_LINK_INERTIA;
+PIH_CONST real L_LO[NL] = PIH_LINK_LO;
+PIH_CONST real L_HI[NL] = PIH_LINK_HI;
+PIH_CONST real L_DAMPING[NL] = PIH_LINK_DAMPING;
+PIH_CONST real L_MU[NL] = PIH_LINK_MU;
+PIH_CONST real ARM_BASE_R[9] = PIH_ARM_BASE_R;
+PIH_CONST real EE_R[9] = PIH_EE_R;
+PIH_CONST real EE_T[3] = PIH_EE_T;
+PIH_CONST real ARM_REST[9] = PIH_ARM_REST;
+PIH_CONST real FBOX_C[2][3] = PIH_FINGER_BOX_C;
+PIH_CONST real FBOX_H[3] = PIH_FINGER_BOX_H;
+PIH_CONST int SAMP_LINK[NSAMP] = PIH_PIPE_SAMP_LINK;
+PIH_CONST real SAMP_Y[NSAMP] = PIH_PIPE_SAMP_Y;
+PIH_CONST int SAMP_VERTEX[NSAMP] = PIH_PIPE_SAMP_VERTEX;
+PIH_CONST real HOLE_POS[3] = PIH_HOLE_POS;
+PIH_CONST real FSM_DUR[10] = {0.25, 2, 2, 1, 1.5, 1.5, 0.5, 0.25, 0.25, 0.25};   // envs/peg_in_hole.py:263
+
+#define PIH_PI ((real)3.14159265358979323846)
+#define PIH_LIN_DAMP ((real)0.04)
+#define PIH_ANG_DAMP ((real)0.04)
+#define PIH_MAX_COORD_VEL ((real)100)
+#define PIH_MAX_FRICTION ((real)10)
+#define PIH_BIG ((real)1e30)
+
+struct Params {
+  real dt, resid, erp, warm, margin, slop, ikdamp, ikres, dv;
+  int iters, ikiters, mode, maxsteps, autoreset, selfcol, debug, env0;
+  uint64_t seed;
+};
+
+// dof index of link L: arm link i -> i ; pipe root (link 9) -> 9..14 (lin xyz, ang xyz) ; pipe link L>=10 -> L+5
+PIH_HD int link_dof(int L) { return L < ANL ? L : (L == ANL ? 9 : L + 5); }
+
+struct Shared {
+  real S[PIH_STATE_WORDS];
+  real Tl[NL][12];                 // local (parent->link) transforms
+  real LR[NL][9], LO[NL][3], LA[NL][3], LRC[NL][3], LIC[NL][6];   // world pose, joint axis, com offset, inertia
+  real VW[NL][3], VV[NL][3];       // link angular velocity, velocity of the link-origin point
+  real IA[NL][21], PA[NL][6];      // articulated inertia (A6 B9 C6) / bias force accumulators
+  real CB[NL][6];                  // velocity-product accelerations
+  real AU[NL][6], ADinv[NL], Au[NL], AR[NL][3];   // U = I^A S, 1/D, u, r = o_L - o_parent
+  real Inv6[36];
+  real u[ND], udot[ND];
+  real SP[NSAMP][3];
+  int c_la[CMAX], c_lb[CMAX], c_key[CMAX], c_arow[CMAX];
+  real c_p[CMAX][3], c_n[CMAX][3], c_depth[CMAX], c_mu[CMAX];
+  int nc, nca;
+  real r_dir[NROWC][3], r_dinv[NROWC], r_rhs[NROWC], r_lam[NROWC];
+  real Wp[NROWC][WPS];
+  real Wa[3 * CAMAX][9];
+  real m_vt[NMOT], m_maximp[NMOT], m_dinv[NMOT], m_rhs[NMOT], m_lam[NMOT];
+  real Wmp[PIH_OBJ_NJ][WPS];
+  real Wma[9][9];
+  real l_rhs[NLIM], l_lam[NLIM];
+  real ik_T[7][12];
+  real scratch[8];
+#ifdef PIH_HOST_EMUL
+  real du[ND];
+#endif
+};
+
+// ------------------------------------------------------------------------------------------------ wave context
+#ifdef PIH_HOST_EMUL
+struct Wave {
+  int lane() const { return 0; }
+  void sync() {}
+  template <class F> void par(int n, F f) { for (int i = 0; i < n; i++) f(i); }
+  // deterministic stream compaction: returns the slot of item i if valid (items are visited in index order)
+  int counter = 0;
+  int alloc(bool valid) { return valid ? counter++ : -1; }
+  void alloc_reset(int base) { counter = base; }
+  int alloc_count() const { return counter; }
+  template <class F> void par_all(int n, F f) { for (int i = 0; i < n; i++) f(i, true); }
+};
+#else
+struct Wave {
+  int l;
+  int counter;
+  PIH_HD int lane() const { return l; }
+  PIH_HD void sync() { __syncthreads(); }
+  template <class F> PIH_HD void par(int n, F f) {
+    __syncthreads();
+    for (int b = 0; b < n; b += 64) { int i = b + l; if (i < n) f(i); }
+    __syncthreads();
+  }
+  // all lanes call f(i, in_range) for every chunk so that wave collectives inside f are legal
+  template <class F> PIH_HD void par_all(int n, F f) {
+    __syncthreads();
+    for (int b = 0; b < n; b += 64) { int i = b + l; f(i, i < n); }
+    __syncthreads();
+  }
+  PIH_HD void alloc_reset(int base) { counter = base; }
+  PIH_HD int alloc_count() const { return counter; }
+  PIH_HD int alloc(bool valid) {   // must be reached by all 64 lanes
+    unsigned long long m = __ballot(valid);
+    int slot = counter + __popcll(m & ((1ull << l) - 1ull));
+    counter += __popcll(m);
+    return valid ? slot : -1;
+  }
+};
+#endif
+
+// ------------------------------------------------------------------------------------------------ kinematics
+// local transform of link L for joint value q (lane = link)
+PIH_HD void local_transform(int L, real q, const real* S, real* T) {
+  int jt = L_JTYPE[L];
+  if (jt == PIH_JT_FLOATING) {
+    Q4 qq; qq.x = S[PIH_S_QUAT]; qq.y = S[PIH_S_QUAT + 1]; qq.z = S[PIH_S_QUAT + 2]; qq.w = S[PIH_S_QUAT + 3];
+    M3 R = q_to_m(qq); stm(T, R); T[9] = S[PIH_S_POS]; T[10] = S[PIH_S_POS + 1]; T[11] = S[PIH_S_POS + 2];
+    return;
+  }
+  M3 Rf = ldm(L_RFIX[L]); V3 ax = ld3(L_AXIS[L]); V3 t = ld3(L_TFIX[L]);
+  if (jt == PIH_JT_REVOLUTE) { M3 R = mul(Rf, axis_angle(ax, q)); stm(T, R); st3(T + 9, t); }
+  else { stm(T, Rf); st3(T + 9, t + q * mul(Rf, ax)); }
+}
+
+template <class W> PIH_HD void fk_all(W& w, Shared& sh) {
+  w.par(NL, [&](int L) {
+    real q = L < ANL ? sh.S[PIH_S_QARM + L] : (L == ANL ? (real)0 : sh.S[PIH_S_QJ + L - ANL - 1]);
+    local_transform(L, q, sh.S, sh.Tl[L]);
+  });
+  // serial composition down the two chains (wave-uniform)
+  for (int L = 0; L < NL; L++) {
+    int p = L_PARENT[L];
+    M3 Tl = ldm(sh.Tl[L]); V3 tl = ld3(sh.Tl[L] + 9);
+    M3 R; V3 o;
+    if (L_JTYPE[L] == PIH_JT_FLOATING) { R = Tl; o = tl; }
+    else if (p < 0) { M3 Rp = ldm(ARM_BASE_R); R = mul(Rp, Tl); o = mul(Rp, tl); }
+    else { M3 Rp = ldm(sh.LR[p]); R = mul(Rp, Tl); o = ld3(sh.LO[p]) + mul(Rp, tl); }
+    stm(sh.LR[L], R); st3(sh.LO[L], o);
+  }
+  w.par(NL, [&](int L) {
+    M3 R = ldm(sh.LR[L]);
+    st3(sh.LA[L], mul(R, ld3(L_AXIS[L])));
+    st3(sh.LRC[L], mul(R, ld3(L_COM[L])));
+    sts3(sh.LIC[L], rot_sym(R, lds3(L_INERTIA[L])));
+  });
+}
+PIH_HD void ee_pose(const Shared& sh, V3& p, M3& R) {
+  M3 Rp = ldm(sh.LR[PIH_EE_PARENT]);
+  R = mul(Rp, ldm(EE_R)); p = ld3(sh.LO[PIH_EE_PARENT]) + mul(Rp, ld3(EE_T));
+}
+// getLinkState(pipe, grasp_joint_idx)[0:2]: COM frame of pipe_link1 (idx 0) / pipe_link24 (idx 23)
+PIH_HD void tip_pose(const Shared& sh, real* out) {
+  int g = (int)sh.S[PIH_S_GRASP];
+  int L = g == 0 ? ANL : NL - 1;
+  M3 R = ldm(sh.LR[L]);
+  V3 p = ld3(sh.LO[L]) + mul(R, mk(0, g == 0 ? (real)0.045 : (real)0.015, 0));
+  Q4 q = m_to_q(R);
+  out[0] = p.x; out[1] = p.y; out[2] = p.z; out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
+}
+
+// ------------------------------------------------------------------------------------------------ IK (p2)
+// BussIK DLS as driven by pybullet.calculateInverseKinematics without null-space arguments [UNVERIFIED restatement]:
+// dq = (J^T J + d I)^-1 J^T e over all 9 movable DOF (finger columns are zero => 7x7), |dq|_inf <= 30 deg.
+template <class W> PIH_HD void ik_solve(W& w, Shared& sh, const Params& P, const real* q0, V3 tpos, Q4 tq, real* qout) {
+  real q[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) q[i] = q0[i];
+  const real maxstep = (real)(30.0 * 3.14159265358979323846 / 180.0);
+  for (int it = 0; it < P.ikiters; it++) {
+    w.par(7, [&](int L) {
+      real qq = q[0];
+#pragma unroll
+      for (int k = 1; k < 7; k++) qq = (L == k) ? q[k] : qq;
+      local_transform(L, qq, sh.S, sh.ik_T[L]);
+    });
+    V3 a[7], o[7];
+    M3 R = ldm(ARM_BASE_R); V3 org = mk(0, 0, 0);
+#pragma unroll
+    for (int L = 0; L < 7; L++) {
+      M3 Tl = ldm(sh.ik_T[L]); V3 tl = ld3(sh.ik_T[L] + 9);
+      org = org + mul(R, tl); R = mul(R, Tl);
+      o[L] = org; a[L] = col(R, 2);    // every arm joint axis is local z
+    }
+    M3 Re = mul(R, ldm(EE_R)); V3 p = org + mul(R, ld3(EE_T));
+    Q4 cq = m_to_q(Re);
+    V3 ep = tpos - p;
+    if (norm(ep) < P.ikres) break;
+    Q4 ci; ci.x = -cq.x; ci.y = -cq.y; ci.z = -cq.z; ci.w = cq.w;
+    Q4 dq = q_mul(tq, ci);
+    // Bullet: angle = 2 acos(w) wrapped to (-pi, pi], axis = xyz / sqrt(1 - w^2).  For a unit quaternion this equals
+    // 2 atan2(|xyz|, w) and xyz/|xyz|, which (unlike acos near w = 1) is well conditioned in fp32.
+    V3 dv3 = mk(dq.x, dq.y, dq.z);
+    real sn = norm(dv3), ang = 2 * (real)atan2(sn, dq.w);
+    V3 ax = sn < (real)1e-12 ? mk(1, 0, 0) : ((real)1 / sn) * dv3;
+    if (ang > PIH_PI) ang -= 2 * PIH_PI;
+    V3 er = ang * ax;
+    V3 jl[7];
+    real b[7], A[7][7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) { jl[j] = cross(a[j], p - o[j]); b[j] = dot(jl[j], ep) + dot(a[j], er); }
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) A[i][j] = dot(jl[i], jl[j]) + dot(a[i], a[j]) + (i == j ? P.ikdamp : (real)0);
+    // Cholesky (lower) + solve, fully unrolled
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      real s = A[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= A[j][k] * A[j][k];
+      real d = (real)sqrt(s); A[j][j] = d; real di = (real)1 / d;
+#pragma unroll
+      for (int i = j + 1; i < 7; i++) {
+        real t = A[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k];
+        A[i][j] = t * di;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) { real s = b[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) s -= A[i][k] * b[k];
+      b[i] = s / A[i][i]; }
+#pragma unroll
+    for (int i = 6; i >= 0; i--) { real s = b[i];
+#pragma unroll
+      for (int k = i + 1; k < 7; k++) s -= A[k][i] * b[k];
+      b[i] = s / A[i][i]; }
+    real mx = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) mx = absr(b[i]) > mx ? absr(b[i]) : mx;
+    real sc = mx > maxstep ? maxstep / mx : (real)1;
+#pragma unroll
+    for (int i = 0; i < 7; i++) q[i] += sc * b[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 7; i++) qout[i] = q[i];
+}
+
+// ------------------------------------------------------------------------------------------------ reset
+// envs/peg_in_hole.py:227-274 with the RNG draw order of SURVEY.md App. E (own counter RNG).  Wave-uniform.
+PIH_HD void reset_state(real* S, const Params& P, int env_global) {
+  real off0 = S[PIH_S_OFFSET], off1 = S[PIH_S_OFFSET + 1], off2 = S[PIH_S_OFFSET + 2];
+  uint64_t ctr = (uint64_t)S[PIH_S_RNG];
+  uint64_t seed = P.seed + 1000ULL + (uint64_t)env_global;
+  for (int i = 0; i < PIH_STATE_WORDS; i++) S[i] = 0;
+  S[PIH_S_OFFSET] = off0; S[PIH_S_OFFSET + 1] = off1; S[PIH_S_OFFSET + 2] = off2;
+  for (int i = 0; i < 9; i++) { S[PIH_S_QARM + i] = ARM_REST[i]; S[PIH_S_TARGET + i] = ARM_REST[i]; }
+  const real U = (real)(1.0 / 16777216.0);
+  S[PIH_S_POS] = (real)-0.2 + (real)0.4 * ((real)rng24(seed, ctr++) * U);
+  S[PIH_S_POS + 1] = (real)-0.4 - (real)0.2 * ((real)rng24(seed, ctr++) * U);
+  S[PIH_S_POS + 2] = (real)0.11;
+  S[PIH_S_QUAT + 3] = 1;
+  int k = 5 + (int)(((uint64_t)rng24(seed, ctr++) * 20ULL) >> 24);
+  // partial Fisher-Yates over 24 joint indices, kept as a 24 x 5-bit packed permutation to stay in registers
+  uint64_t lo = 0, hi = 0;   // entries 0..11 in lo, 12..23 in hi (5 bits each)
+  for (int i = 0; i < 12; i++) { lo |= (uint64_t)i << (5 * i); hi |= (uint64_t)(i + 12) << (5 * i); }
+  auto get = [&](int i) -> int { return i < 12 ? (int)((lo >> (5 * i)) & 31) : (int)((hi >> (5 * (i - 12))) & 31); };
+  auto set = [&](int i, int v) {
+    if (i < 12) lo = (lo & ~(31ULL << (5 * i))) | ((uint64_t)v << (5 * i));
+    else hi = (hi & ~(31ULL << (5 * (i - 12)))) | ((uint64_t)v << (5 * (i - 12)));
+  };
+  for (int i = 0; i < k; i++) {
+    int j = i + (int)(((uint64_t)rng24(seed, ctr++) * (uint64_t)(24 - i)) >> 24);
+    int a = get(i), b = get(j); set(i, b); set(j, a);
+  }
+  for (int i = 0; i < k; i++) {
+    real a = (real)(3.14159265358979323846 / 3.0) * ((real)rng24(seed, ctr++) * U);
+    int idx = get(i);
+    if (idx >= 1) S[PIH_S_QJ + idx - 1] = a;
+  }
+  S[PIH_S_GRASP] = (rng24(seed, ctr++) >> 23) ? (real)23 : (real)0;
+  S[PIH_S_RANDY] = (real)-0.03 + (real)0.06 * ((real)rng24(seed, ctr++) * U);
+  S[PIH_S_RNG] = (real)ctr;
+}
+
+// ------------------------------------------------------------------------------------------------ controller
+template <class W> PIH_HD void controller(W& w, Shared& sh, const Params& P, const real* action) {
+  real* S = sh.S;
+  V3 eep; M3 eeR; ee_pose(sh, eep, eeR);
+  int posctl_arm = 0; real kp_arm = 0, imp_arm = 1, kp_f = 0, imp_f = 1; int posctl_f = 0;
+  if (P.mode == 0) {
+    // panda_execute, envs/utils.py:60-68
+    V3 tl = mk(action[0] - S[PIH_S_OFFSET], action[1] - S[PIH_S_OFFSET + 1], action[2] - S[PIH_S_OFFSET + 2]);
+    V3 tp = vel_constraint(eep, tl, P.dv);
+    Q4 tq = quat_from_euler(0, -PIH_PI, 0);
+    real qs[7];
+    ik_solve(w, sh, P, S + PIH_S_QARM, tp, tq, qs);
+#pragma unroll
+    for (int i = 0; i < 7; i++) S[PIH_S_TARGET + i] = qs[i];
+    S[PIH_S_TARGET + 7] = action[3]; S[PIH_S_TARGET + 8] = action[3];
+    posctl_arm = posctl_f = 1; kp_arm = kp_f = 1; imp_arm = imp_f = (real)100000.0 * P.dt;
+  } else {
+    // random_grasp loop body, envs/peg_in_hole.py:53-112 (update_state :206-212, grasp_process :122-204)
+    int st = (int)S[PIH_S_FSM];
+    real t = S[PIH_S_FSMT] + P.dt;
+    if (t > FSM_DUR[st]) { st += 1; t = 0; if (st >= 10) st = 0; }
+    S[PIH_S_FSM] = (real)st; S[PIH_S_FSMT] = t;
+    real tip[7]; tip_pose(sh, tip);
+    Q4 tornq; tornq.x = tip[3]; tornq.y = tip[4]; tornq.z = tip[5]; tornq.w = tip[6];
+    V3 rv = mul(q_to_m(tornq), mk(0, S[PIH_S_RANDY], 0));
+    V3 tpos = mk(tip[0], tip[1], tip[2]) + rv;
+    V3 tp = vel_constraint(eep, tpos, P.dv);
+    real yaw = yaw_from_quat(tornq);
+    V3 hole = ld3(HOLE_POS);
+    Q4 tq; tq.x = 0; tq.y = 0; tq.z = 0; tq.w = 1;
+    int do_ik = 0;
+    if (st == 1) { tp.z += (real)0.05; tq = quat_from_euler(0, -PIH_PI, PIH_PI / 2 + yaw); do_ik = 1; }
+    else if (st == 2) { tp.z -= (real)0.01; tq = quat_from_euler(0, -PIH_PI, PIH_PI / 2 + yaw); do_ik = 1; }
+    else if (st == 4) { tp = vel_constraint(eep, hole - mk((real)0.2, 0, 0), P.dv); tq = quat_from_euler(0, -PIH_PI, -PIH_PI); do_ik = 1; }
+    else if (st == 5) { tp = vel_constraint(eep, hole - mk((real)0.04, 0, 0), P.dv); tq = quat_from_euler(0, -PIH_PI, -PIH_PI); do_ik = 1; }
+    else if (st == 6) { tp = hole; tq = quat_from_euler(0, -PIH_PI, -PIH_PI); do_ik = 1; }
+    else if (st == 8) { tp = mk((real)0.2, (real)-0.6, (real)0.4); tq = quat_from_euler(0, -PIH_PI, PIH_PI / 2); do_ik = 1; }
+    else if (st == 9) S[PIH_S_DONE] = 1;
+    if (do_ik) {
+      real qs[7];
+      ik_solve(w, sh, P, S + PIH_S_QARM, tp, tq, qs);
+#pragma unroll
+      for (int i = 0; i < 7; i++) S[PIH_S_TARGET + i] = qs[i];
+    }
+    if (st >= 1) { posctl_arm = 1; kp_arm = (real)0.1; imp_arm = (real)(5.0 * 240.0) * P.dt; }
+    bool closed = st >= 3 && st < 7;
+    real ft = closed ? (real)0.006 : (real)0.02;
+    posctl_f = 1; kp_f = (real)0.1; imp_f = (closed ? (real)20000 : (real)20) * P.dt;
+    S[PIH_S_TARGET + 7] = ft; S[PIH_S_TARGET + 8] = ft;
+  }
+  // motor rows: btMultiBodyJointMotor desired velocity = kp (q* - q)/dt (+ qd - kd qd, kd = 1); default load-time
+  // velocity motor (target 0, max impulse 1) on every joint that was never commanded (all 23 pipe joints)
+  w.par(NMOT, [&](int m) {
+    real vt = 0, imp = 1;
+    if (m < 7) { if (posctl_arm) { vt = kp_arm * (S[PIH_S_TARGET + m] - S[PIH_S_QARM + m]) / P.dt; imp = imp_arm; } }
+    else if (m < 9) { if (posctl_f) { vt = kp_f * (S[PIH_S_TARGET + m] - S[PIH_S_QARM + m]) / P.dt; imp = imp_f; } }
+    sh.m_vt[m] = vt; sh.m_maximp[m] = imp;
+  });
+}
+
+// ------------------------------------------------------------------------------------------------ collision
+template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
+  const real r = (real)PIH_PIPE_RADIUS, margin = P.margin;
+  w.par(NSAMP, [&](int i) {
+    int L = ANL + SAMP_LINK[i];
+    V3 p = ld3(sh.LO[L]) + mul(ldm(sh.LR[L]), mk(0, SAMP_Y[i], 0));
+    st3(sh.SP[i], p);
+  });
+  auto emit = [&](int slot, int la, int lb, int key, V3 p, V3 n, real depth, real mu) {
+    sh.c_la[slot] = la; sh.c_lb[slot] = lb; sh.c_key[slot] = key; st3(sh.c_p[slot], p); st3(sh.c_n[slot], n);
+    sh.c_depth[slot] = depth; sh.c_mu[slot] = clampr(mu, -PIH_MAX_FRICTION, PIH_MAX_FRICTION);
+  };
+  w.alloc_reset(0);
+  // table plane: vertices only
+  w.par_all(NSAMP, [&](int i, bool in) {
+    bool valid = false; V3 sp = mk(0, 0, 0); real depth = 0; int L = 0;
+    if (in && SAMP_VERTEX[i]) {
+      sp = ld3(sh.SP[i]); depth = sp.z - (real)PIH_TABLE_Z - r; L = ANL + SAMP_LINK[i];
+      valid = depth < margin;
+    }
+    int slot = w.alloc(valid);
+    if (valid && slot < CMAX) {
+      int vi = 0;   // vertex ordinal = key
+      { int s = SAMP_LINK[i]; vi = SAMP_Y[i] > (real)0.02 && s == 23 ? 24 : s; }
+      emit(slot, L, -1, vi, mk(sp.x, sp.y, sp.z - r - (real)0.5 * depth), mk(0, 0, 1), depth, L_MU[L] * (real)PIH_TABLE_MU);
+    }
+  });
+  // hole tube: exact SDF of the solid of revolution of a rectangle in (axial a, radial rho)
+  const real hl = (real)PIH_HOLE_HALFLEN, rcx = (real)(0.5 * (PIH_HOLE_RIN + PIH_HOLE_ROUT)), hw = (real)(0.5 * (PIH_HOLE_ROUT - PIH_HOLE_RIN));
+  w.par_all(NSAMP, [&](int i, bool in) {
+    bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = 0; int L = 0;
+    if (in) {
+      V3 sp = ld3(sh.SP[i]); V3 d = sp - ld3(HOLE_POS);
+      real a = d.x, rho = (real)sqrt(d.y * d.y + d.z * d.z);
+      real dx = absr(a) - hl, dy = absr(rho - rcx) - hw;
+      if (!(dx > r + margin || dy > r + margin)) {
+        real sa = a >= 0 ? (real)1 : (real)-1, sr = rho >= rcx ? (real)1 : (real)-1, ga, gr, sdf;
+        if (dx <= 0 && dy <= 0) { if (dx > dy) { ga = sa; gr = 0; sdf = dx; } else { ga = 0; gr = sr; sdf = dy; } }
+        else { real mx = dx > 0 ? dx : 0, my = dy > 0 ? dy : 0; sdf = (real)sqrt(mx * mx + my * my); ga = sa * mx / sdf; gr = sr * my / sdf; }
+        depth = sdf - r;
+        if (depth < margin) {
+          V3 rh = rho > (real)1e-9 ? mk(0, d.y / rho, d.z / rho) : mk(0, 1, 0);
+          n = mk(ga, gr * rh.y, gr * rh.z); p = sp - (r + (real)0.5 * depth) * n; L = ANL + SAMP_LINK[i]; valid = true;
+        }
+      }
+    }
+    int slot = w.alloc(valid);
+    if (valid && slot < CMAX) emit(slot, L, -1, 100 + i, p, n, depth, L_MU[L] * (real)PIH_HOLE_MU);
+  });
+  // finger pad boxes (arm links 7, 8)
+  int nca = 0;
+  for (int f = 0; f < 2; f++) {
+    const int LF = PIH_FINGER_LINK0 + f;
+    M3 Rf = ldm(sh.LR[LF]); V3 bc = ld3(sh.LO[LF]) + mul(Rf, ld3(FBOX_C[f])); V3 bh = ld3(FBOX_H);
+    const int before = w.alloc_count();
+    const int allowed = CAMAX - nca;   // arm-involving contacts are capped (their arm response rows live in Wa)
+    w.par_all(NSAMP, [&](int i, bool in) {
+      bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = 0; int L = 0;
+      if (in) {
+        V3 sp = ld3(sh.SP[i]); V3 d = sp - bc;
+        if (dot(d, d) <= (real)(0.05 * 0.05)) {
+          V3 pl = tmul(Rf, d);
+          V3 q = mk(clampr(pl.x, -bh.x, bh.x), clampr(pl.y, -bh.y, bh.y), clampr(pl.z, -bh.z, bh.z));
+          bool inside = q.x == pl.x && q.y == pl.y && q.z == pl.z;
+          V3 nl; real sdf;
+          if (inside) {
+            real bx = bh.x - absr(pl.x), by = bh.y - absr(pl.y), bz = bh.z - absr(pl.z);
+            int ax = 0; real best = bx;
+            if (by < best) { best = by; ax = 1; }
+            if (bz < best) { best = bz; ax = 2; }
+            nl = mk(ax == 0 ? (pl.x >= 0 ? (real)1 : (real)-1) : 0, ax == 1 ? (pl.y >= 0 ? (real)1 : (real)-1) : 0, ax == 2 ? (pl.z >= 0 ? (real)1 : (real)-1) : 0);
+            sdf = -best;
+          } else { V3 df = pl - q; sdf = norm(df); nl = ((real)1 / sdf) * df; }
+          depth = sdf - r;
+          if (depth < margin) { n = mul(Rf, nl); p = sp - (r + (real)0.5 * depth) * n; L = ANL + SAMP_LINK[i]; valid = true; }
+        }
+      }
+      int slot = w.alloc(valid);
+      if (valid && slot < CMAX && (slot - before) < allowed) emit(slot, L, LF, 300 + f * NSAMP + i, p, n, depth, L_MU[L] * L_MU[LF]);
+    });
+    int used = w.alloc_count() - before;
+    if (used > allowed) { used = allowed; w.alloc_reset(before + allowed); }   // the dropped ones are the tail of this pass
+    nca += used;
+  }
+  // pipe self collision: capsule segments s < t, non adjacent (253 pairs, enumerated in key order)
+  if (P.selfcol) {
+    w.par_all(253, [&](int idx, bool in) {
+      bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = 0; int s = 0, t = 0;
+      if (in) {
+        // idx -> (s,t): row s has (22 - s) entries (t = s+2..23)
+        int rem = idx; s = 0;
+        while (rem >= 22 - s) { rem -= 22 - s; s++; }
+        t = s + 2 + rem;
+        // vertex v = first sample of segment v (v<24) / last sample (v=24): sample index of vertex v
+        auto vtx = [&](int v) -> V3 { int si = v == 0 ? 0 : (v == 24 ? NSAMP - 1 : 7 + 5 * (v - 1)); return ld3(sh.SP[si]); };
+        V3 p1 = vtx(s), q1 = vtx(s + 1), p2 = vtx(t), q2 = vtx(t + 1);
+        V3 dm = (p1 + q1) - (p2 + q2);
+        if (dot(dm, dm) <= (real)(4 * 0.12 * 0.12)) {
+          V3 d1 = q1 - p1, d2 = q2 - p2, rr = p1 - p2;
+          real a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, rr), ss, tt;
+          const real EPS = (real)1e-12;
+          if (a <= EPS && e <= EPS) { ss = tt = 0; }
+          else if (a <= EPS) { ss = 0; tt = clampr(f / e, 0, 1); }
+          else {
+            real c = dot(d1, rr);
+            if (e <= EPS) { tt = 0; ss = clampr(-c / a, 0, 1); }
+            else {
+              real b = dot(d1, d2), den = a * e - b * b;
+              ss = den > EPS ? clampr((b * f - c * e) / den, 0, 1) : (real)0;
+              tt = (b * ss + f) / e;
+              if (tt < 0) { tt = 0; ss = clampr(-c / a, 0, 1); } else if (tt > 1) { tt = 1; ss = clampr((b - c) / a, 0, 1); }
+            }
+          }
+          V3 c1 = p1 + ss * d1, c2 = p2 + tt * d2, d = c1 - c2;
+          real dist = norm(d); depth = dist - 2 * r;
+          if (depth < margin && dist >= (real)1e-9) { n = ((real)1 / dist) * d; p = (real)0.5 * (c1 + c2); valid = true; }
+        }
+      }
+      int slot = w.alloc(valid);
+      if (valid && slot < CMAX) emit(slot, ANL + s, ANL + t, 1000 + s * 24 + t, p, n, depth, L_MU[ANL + s] * L_MU[ANL + t]);
+    });
+  }
+  int nc = w.alloc_count(); if (nc > CMAX) nc = CMAX;
+  sh.nc = nc; sh.nca = nca;
+}
+
+// ------------------------------------------------------------------------------------------------ ABA
+// link velocities from the generalized velocity sh.u (wave-uniform serial sweep)
+PIH_HD void link_velocities(Shared& sh) {
+  for (int L = 0; L < NL; L++) {
+    int p = L_PARENT[L], jt = L_JTYPE[L], d = link_dof(L);
+    V3 wv, vv;
+    if (jt == PIH_JT_FLOATING) { vv = ld3(&sh.u[d]); wv = ld3(&sh.u[d + 3]); }
+    else {
+      V3 wp = mk(0, 0, 0), vat = mk(0, 0, 0);
+      if (p >= 0) { wp = ld3(sh.VW[p]); vat = ld3(sh.VV[p]) + cross(wp, ld3(sh.LO[L]) - ld3(sh.LO[p])); }
+      V3 aq = sh.u[d] * ld3(sh.LA[L]);
+      if (jt == PIH_JT_REVOLUTE) { wv = wp + aq; vv = vat; } else { wv = wp; vv = vat + aq; }
+    }
+    st3(sh.VW[L], wv); st3(sh.VV[L], vv);
+  }
+}
+
+// Articulated-body algorithm; leaves U, 1/D, r per link and the inverse root inertia for the impulse responses,
+// and the free acceleration in sh.udot.
+template <class W> PIH_HD void aba(W& w, Shared& sh) {
+  link_velocities(sh);
+  // per-link spatial inertia about the link origin, velocity-product acceleration and bias force (lane = link)
+  w.par(NL, [&](int L) {
+    int p = L_PARENT[L], jt = L_JTYPE[L];
+    real m = L_MASS[L];
+    V3 rc = ld3(sh.LRC[L]); S3 Ic = lds3(sh.LIC[L]);
+    V3 wv = ld3(sh.VW[L]), vv = ld3(sh.VV[L]);
+    // A = Ic + m (|rc|^2 1 - rc rc^T), B = m [rc]x, C = m 1
+    real* I = sh.IA[L];
+    real r2 = dot(rc, rc);
+    I[0] = Ic.xx + m * (r2 - rc.x * rc.x); I[1] = Ic.yy + m * (r2 - rc.y * rc.y); I[2] = Ic.zz + m * (r2 - rc.z * rc.z);
+    I[3] = Ic.xy - m * rc.x * rc.y; I[4] = Ic.xz - m * rc.x * rc.z; I[5] = Ic.yz - m * rc.y * rc.z;
+    I[6] = 0; I[7] = -m * rc.z; I[8] = m * rc.y; I[9] = m * rc.z; I[10] = 0; I[11] = -m * rc.x; I[12] = -m * rc.y; I[13] = m * rc.x; I[14] = 0;
+    I[15] = m; I[16] = m; I[17] = m; I[18] = 0; I[19] = 0; I[20] = 0;
+    // velocity-product acceleration c
+    V3 ca = mk(0, 0, 0), cl = mk(0, 0, 0), r = mk(0, 0, 0);
+    if (jt != PIH_JT_FLOATING && p >= 0) {
+      V3 wp = ld3(sh.VW[p]); r = ld3(sh.LO[L]) - ld3(sh.LO[p]);
+      V3 aq = sh.u[link_dof(L)] * ld3(sh.LA[L]);
+      cl = cross(wp, cross(wp, r));
+      if (jt == PIH_JT_REVOLUTE) ca = cross(wp, aq); else cl = cl + (real)2 * cross(wp, aq);
+    }
+    st3(sh.CB[L], ca); st3(sh.CB[L] + 3, cl); st3(sh.AR[L], r);
+    // bias force: velocity products minus gravity minus Bullet link damping
+    V3 wrc = cross(wv, rc);
+    V3 vc = vv + wrc;
+    V3 Iw = mul(Ic, wv);
+    real sv = PIH_LIN_DAMP + PIH_LIN_DAMP * norm(vc), sw = PIH_ANG_DAMP + PIH_ANG_DAMP * norm(wv);
+    V3 f = m * cross(wv, wrc) - mk(0, 0, m * (real)PIH_GRAVITY_Z) + (m * sv) * vc;
+    V3 n = cross(wv, Iw) + sw * Iw + cross(rc, f);
+    st3(sh.PA[L], n); st3(sh.PA[L] + 3, f);
+  });
+  // inward sweep (wave-uniform)
+  for (int L = NL - 1; L >= 0; L--) {
+    int p = L_PARENT[L], jt = L_JTYPE[L];
+    const real* I = sh.IA[L];
+    S3 A = lds3(I); M3 B = ldm(I + 6); S3 C = lds3(I + 15);
+    V3 pa = ld3(sh.PA[L]), pl = ld3(sh.PA[L] + 3);
+    if (jt == PIH_JT_FLOATING) {
+      // root: invert the 6x6 articulated inertia [[A,B],[B^T,C]] (order: angular, linear) by Gauss-Jordan on SPD
+      real Mx[6][6];
+      M3 Am = s3_to_m(A), Cm = s3_to_m(C);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Mx[i][j] = Am.m[3 * i + j]; Mx[i][3 + j] = B.m[3 * i + j]; Mx[3 + i][j] = B.m[3 * j + i]; Mx[3 + i][3 + j] = Cm.m[3 * i + j]; }
+      real Iv[6][6];
+      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Iv[i][j] = i == j ? (real)1 : (real)0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        real pv = (real)1 / Mx[k][k];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { Mx[k][j] *= pv; Iv[k][j] *= pv; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i != k) {
+          real f = Mx[i][k];
+#pragma unroll
+          for (int j = 0; j < 6; j++) { Mx[i][j] -= f * Mx[k][j]; Iv[i][j] -= f * Iv[k][j]; }
+        }
+      }
+      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.Inv6[6 * i + j] = Iv[i][j];
+      continue;
+    }
+    V3 a = ld3(sh.LA[L]);
+    V3 Ua, Ul; real D, u;
+    real tau = -L_DAMPING[L] * sh.u[link_dof(L)];
+    if (jt == PIH_JT_REVOLUTE) { Ua = mul(A, a); Ul = tmul(B, a); D = dot(a, Ua); u = tau - dot(a, pa); }
+    else { Ua = mul(B, a); Ul = mul(C, a); D = dot(a, Ul); u = tau - dot(a, pl); }
+    real Di = (real)1 / D;
+    st3(sh.AU[L], Ua); st3(sh.AU[L] + 3, Ul); sh.ADinv[L] = Di; sh.Au[L] = u;
+    if (p < 0) continue;   // arm root: parent is the fixed world
+    // I^a = I^A - U U^T / D
+    sub_outer(A, Ua, Di); sub_outer(C, Ul, Di);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { real ui = i == 0 ? Ua.x : (i == 1 ? Ua.y : Ua.z); B.m[3 * i] -= ui * Ul.x * Di; B.m[3 * i + 1] -= ui * Ul.y * Di; B.m[3 * i + 2] -= ui * Ul.z * Di; }
+    // p^a = p^A + I^a c + U u / D
+    V3 ca = ld3(sh.CB[L]), cl = ld3(sh.CB[L] + 3);
+    real ud = u * Di;
+    V3 qa = pa + mul(A, ca) + mul(B, cl) + ud * Ua;
+    V3 ql = pl + tmul(B, ca) + mul(C, cl) + ud * Ul;
+    // translate to the parent's origin: r = o_L - o_p
+    V3 r = ld3(sh.AR[L]);
+    M3 Cm = s3_to_m(C);
+    M3 Bt; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Bt.m[3 * i + j] = B.m[3 * j + i];
+    M3 X = skew_mul(r, Bt);              // [r]x B^T
+    M3 Bn = skew_mul(r, Cm);             // [r]x C
+    for (int i = 0; i < 9; i++) Bn.m[i] += B.m[i];   // B' = B + [r]x C
+    M3 Y = mul_skew(Bn, r);              // B' [r]x
+    real* Ip = sh.IA[p];
+    Ip[0] += A.xx + X.m[0] - Y.m[0]; Ip[1] += A.yy + X.m[4] - Y.m[4]; Ip[2] += A.zz + X.m[8] - Y.m[8];
+    Ip[3] += A.xy + (real)0.5 * ((X.m[1] - Y.m[1]) + (X.m[3] - Y.m[3]));
+    Ip[4] += A.xz + (real)0.5 * ((X.m[2] - Y.m[2]) + (X.m[6] - Y.m[6]));
+    Ip[5] += A.yz + (real)0.5 * ((X.m[5] - Y.m[5]) + (X.m[7] - Y.m[7]));
+    for (int i = 0; i < 9; i++) Ip[6 + i] += Bn.m[i];
+    Ip[15] += C.xx; Ip[16] += C.yy; Ip[17] += C.zz; Ip[18] += C.xy; Ip[19] += C.xz; Ip[20] += C.yz;
+    V3 qn = qa + cross(r, ql);
+    real* Pp = sh.PA[p];
+    Pp[0] += qn.x; Pp[1] += qn.y; Pp[2] += qn.z; Pp[3] += ql.x; Pp[4] += ql.y; Pp[5] += ql.z;
+  }
+  // outward sweep: accelerations (wave-uniform).  VW/VV are reused to carry (alpha, acc) of each link.
+  for (int L = 0; L < NL; L++) {
+    int p = L_PARENT[L], jt = L_JTYPE[L], d = link_dof(L);
+    V3 al, ac;
+    if (jt == PIH_JT_FLOATING) {
+      real pv[6]; for (int i = 0; i < 6; i++) pv[i] = sh.PA[L][i];
+      real x[6];
+      for (int i = 0; i < 6; i++) { real s = 0; for (int j = 0; j < 6; j++) s -= sh.Inv6[6 * i + j] * pv[j]; x[i] = s; }
+      al = mk(x[0], x[1], x[2]); ac = mk(x[3], x[4], x[5]);
+      sh.udot[d] = ac.x; sh.udot[d + 1] = ac.y; sh.udot[d + 2] = ac.z; sh.udot[d + 3] = al.x; sh.udot[d + 4] = al.y; sh.udot[d + 5] = al.z;
+    } else {
+      V3 alp = mk(0, 0, 0), acp = mk(0, 0, 0);
+      if (p >= 0) { alp = ld3(sh.CB[p]); acp = ld3(sh.CB[p] + 3); }   // parent's (alpha, acc) stored below
+      V3 r = ld3(sh.AR[L]);
+      V3 aa = alp + ld3(sh.CB[L]);
+      V3 ll = acp + cross(alp, r) + ld3(sh.CB[L] + 3);
+      V3 Ua = ld3(sh.AU[L]), Ul = ld3(sh.AU[L] + 3);
+      real qdd = (sh.Au[L] - dot(Ua, aa) - dot(Ul, ll)) * sh.ADinv[L];
+      V3 a = ld3(sh.LA[L]);
+      if (jt == PIH_JT_REVOLUTE) { al = aa + qdd * a; ac = ll; } else { al = aa; ac = ll + qdd * a; }
+      sh.udot[d] = qdd;
+    }
+    // overwrite this link's c with its (alpha, acc): c of a link is never needed again once it has been visited
+    st3(sh.CB[L], al); st3(sh.CB[L] + 3, ac);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ constraint rows
+// Unit-impulse response of the articulated system (lane = row): impulse `dirA` at point p on link la, `-dirA` on lb
+// (either may be -1), or a unit joint impulse on the joint of link jm.  Writes the arm part (9) and pipe part (29)
+// of W = M^-1 J^T and returns J W (the inverse effective mass of the row).
+struct RowOut { real* wa; real* wp; };
+PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, RowOut out) {
+  real jw = 0;
+  bool arm = (la >= 0 && la < ANL) || (lb >= 0 && lb < ANL) || (jm >= 0 && jm < ANL);
+  bool obj = (la >= ANL) || (lb >= ANL) || (jm >= ANL);
+  if (arm && out.wa) {
+    V3 Qa[ANL], Ql[ANL]; real uu[ANL];
+#pragma unroll
+    for (int L = 0; L < ANL; L++) { Qa[L] = mk(0, 0, 0); Ql[L] = mk(0, 0, 0); }
+#pragma unroll
+    for (int L = ANL - 1; L >= 0; L--) {
+      if (L == la) { Qa[L] = Qa[L] + cross(p - ld3(sh.LO[L]), dir); Ql[L] = Ql[L] + dir; }
+      if (L == lb) { Qa[L] = Qa[L] - cross(p - ld3(sh.LO[L]), dir); Ql[L] = Ql[L] - dir; }
+      V3 a = ld3(sh.LA[L]);
+      constexpr int JT[ANL] = {0, 0, 0, 0, 0, 0, 0, 1, 1};
+      constexpr int PAR[ANL] = {-1, 0, 1, 2, 3, 4, 5, 6, 6};
+      real u = (L == jm ? (real)1 : (real)0) + (JT[L] == 0 ? dot(a, Qa[L]) : dot(a, Ql[L]));
+      uu[L] = u;
+      if (PAR[L] >= 0) {
+        real ud = u * sh.ADinv[L];
+        V3 qa = Qa[L] - ud * ld3(sh.AU[L]), ql = Ql[L] - ud * ld3(sh.AU[L] + 3);
+        Qa[PAR[L]] = Qa[PAR[L]] + qa + cross(ld3(sh.AR[L]), ql); Ql[PAR[L]] = Ql[PAR[L]] + ql;
+      }
+    }
+    V3 dw[ANL], dvv[ANL];
+#pragma unroll
+    for (int L = 0; L < ANL; L++) {
+      constexpr int JT[ANL] = {0, 0, 0, 0, 0, 0, 0, 1, 1};
+      constexpr int PAR[ANL] = {-1, 0, 1, 2, 3, 4, 5, 6, 6};
+      V3 aa = mk(0, 0, 0), ll = mk(0, 0, 0);
+      if (PAR[L] >= 0) { aa = dw[PAR[L]]; ll = dvv[PAR[L]] + cross(aa, ld3(sh.AR[L])); }
+      real dq = (uu[L] - dot(ld3(sh.AU[L]), aa) - dot(ld3(sh.AU[L] + 3), ll)) * sh.ADinv[L];
+      V3 a = ld3(sh.LA[L]);
+      if (JT[L] == 0) { dw[L] = aa + dq * a; dvv[L] = ll; } else { dw[L] = aa; dvv[L] = ll + dq * a; }
+      out.wa[L] = dq;
+      if (L == jm) jw += dq;
+      if (L == la) jw += dot(dir, dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
+      if (L == lb) jw -= dot(dir, dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
+    }
+  }
+  if (obj && out.wp) {
+    V3 Qa = mk(0, 0, 0), Ql = mk(0, 0, 0); real uu[ONL];
+#pragma unroll
+    for (int j = ONL - 1; j >= 0; j--) {
+      const int L = ANL + j;
+      if (L == la) { Qa = Qa + cross(p - ld3(sh.LO[L]), dir); Ql = Ql + dir; }
+      if (L == lb) { Qa = Qa - cross(p - ld3(sh.LO[L]), dir); Ql = Ql - dir; }
+      if (j > 0) {
+        V3 a = ld3(sh.LA[L]);
+        real u = (L == jm ? (real)1 : (real)0) + dot(a, Qa);
+        uu[j] = u;
+        real ud = u * sh.ADinv[L];
+        V3 qa = Qa - ud * ld3(sh.AU[L]), ql = Ql - ud * ld3(sh.AU[L] + 3);
+        Qa = qa + cross(ld3(sh.AR[L]), ql); Ql = ql;
+      }
+    }
+    // root: (alpha, v) = Inv6 * Q
+    real Q[6] = {Qa.x, Qa.y, Qa.z, Ql.x, Ql.y, Ql.z}, x[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { real s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += sh.Inv6[6 * i + k] * Q[k];
+      x[i] = s; }
+    V3 dw = mk(x[0], x[1], x[2]), dvv = mk(x[3], x[4], x[5]);
+    out.wp[0] = dvv.x; out.wp[1] = dvv.y; out.wp[2] = dvv.z; out.wp[3] = dw.x; out.wp[4] = dw.y; out.wp[5] = dw.z;
+    if (ANL == la) jw += dot(dir, dvv + cross(dw, p - ld3(sh.LO[ANL])));
+    if (ANL == lb) jw -= dot(dir, dvv + cross(dw, p - ld3(sh.LO[ANL])));
+#pragma unroll
+    for (int j = 1; j < ONL; j++) {
+      const int L = ANL + j;
+      V3 ll = dvv + cross(dw, ld3(sh.AR[L]));
+      real dq = (uu[j] - dot(ld3(sh.AU[L]), dw) - dot(ld3(sh.AU[L] + 3), ll)) * sh.ADinv[L];
+      dw = dw + dq * ld3(sh.LA[L]); dvv = ll;
+      out.wp[5 + j] = dq;
+      if (L == jm) jw += dq;
+      if (L == la) jw += dot(dir, dvv + cross(dw, p - ld3(sh.LO[L])));
+      if (L == lb) jw -= dot(dir, dvv + cross(dw, p - ld3(sh.LO[L])));
+    }
+  }
+  return jw;
+}
+
+PIH_HD V3 point_vel(const Shared& sh, int L, V3 p) { return ld3(sh.VV[L]) + cross(ld3(sh.VW[L]), p - ld3(sh.LO[L])); }
+
+template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P) {
+  const real dt = P.dt;
+  // link velocities after the free update (contact / motor right-hand sides)
+  link_velocities(sh);
+  // arm-row slots of arm-involving contacts, in contact order (wave-uniform scan; nc <= 48)
+  {
+    int na = 0;
+    for (int c = 0; c < sh.nc; c++) { int lb = sh.c_lb[c]; bool isarm = lb >= 0 && lb < ANL; sh.c_arow[c] = isarm ? na : -1; na += isarm ? 1 : 0; }
+  }
+  // motor rows (lane = motor): response of a unit joint impulse; limit rows share W and 1/(J W)
+  w.par(NMOT, [&](int m) {
+    int L = m < 9 ? m : ANL + 1 + (m - 9);
+    RowOut o; o.wa = m < 9 ? sh.Wma[m] : nullptr; o.wp = m < 9 ? nullptr : sh.Wmp[m - 9];
+    real jw = response(sh, -1, -1, mk(0, 0, 0), mk(0, 0, 0), L, o);
+    real di = (real)1 / jw;
+    int d = link_dof(L);
+    sh.m_dinv[m] = di; sh.m_rhs[m] = (sh.m_vt[m] - sh.u[d]) * di; sh.m_lam[m] = 0;
+  });
+  w.par(NLIM, [&](int k) {
+    int L = k >> 1, side = k & 1;
+    real q = sh.S[PIH_S_QARM + L];
+    real pen = side == 0 ? q - L_LO[L] : L_HI[L] - q;
+    real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
+    real sg = side == 0 ? (real)1 : (real)-1;
+    sh.l_rhs[k] = (vb - sg * sh.u[L]) * sh.m_dinv[L]; sh.l_lam[k] = 0;
+  });
+  // contact rows (lane = row): row 3c+k, k = 0 normal, 1/2 friction directions
+  w.par(3 * sh.nc, [&](int row) {
+    int c = row / 3, k = row - 3 * c;
+    int la = sh.c_la[c], lb = sh.c_lb[c];
+    V3 n = ld3(sh.c_n[c]), p = ld3(sh.c_p[c]);
+    V3 t1, t2; plane_space(n, t1, t2);
+    V3 dir = k == 0 ? n : (k == 1 ? t1 : t2);
+    st3(sh.r_dir[row], dir);
+    if (la < 0) { sh.r_dinv[row] = 0; sh.r_rhs[row] = 0; sh.r_lam[row] = 0; for (int i = 0; i < 29; i++) sh.Wp[row][i] = 0; return; }
+    int ar = sh.c_arow[c];
+    RowOut o; o.wp = sh.Wp[row]; o.wa = ar >= 0 ? sh.Wa[3 * ar + k] : nullptr;
+    real jw = response(sh, la, lb, p, dir, -1, o);
+    real di = (real)1 / jw;
+    V3 vr = point_vel(sh, la, p);
+    if (lb >= 0) vr = vr - point_vel(sh, lb, p);
+    real ju = dot(dir, vr);
+    real lam = 0, rhs;
+    if (k == 0) {
+      real pen = sh.c_depth[c] + P.slop;
+      real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
+      rhs = (vb - ju) * di;
+      int ncache = (int)sh.S[PIH_S_CACHE_N]; real key = (real)sh.c_key[c];
+      for (int i = 0; i < ncache; i++) if (sh.S[PIH_S_CACHE_KEY + i] == key) { lam = P.warm * sh.S[PIH_S_CACHE_LAMBDA + i]; break; }
+    } else rhs = -ju * di;
+    sh.r_dinv[row] = di; sh.r_rhs[row] = rhs; sh.r_lam[row] = lam;
+  });
+}
+
+// Jacobian entry of DOF d for a translational row (point p on link la minus link lb, direction dir), from the
+// DOF's own axis/origin: revolute-like dir.(a x (p - o)), prismatic-like dir.a
+struct DofGeom { V3 a, o; int L; int kind; };   // kind: 0 rev-like, 1 pris-like, 2 unused lane
+PIH_HD DofGeom dof_geom(const Shared& sh, int d) {
+  DofGeom g; g.a = mk(0, 0, 0); g.o = mk(0, 0, 0); g.L = 0; g.kind = 2;
+  if (d < 9) { g.L = d; g.a = ld3(sh.LA[d]); g.o = ld3(sh.LO[d]); g.kind = d < 7 ? 0 : 1; }
+  else if (d < 15) { int k = d - 9; g.L = ANL; g.o = ld3(sh.LO[ANL]); int kk = k % 3; g.a = mk(kk == 0, kk == 1, kk == 2); g.kind = k < 3 ? 1 : 0; }
+  else if (d < ND) { g.L = d - 5; g.a = ld3(sh.LA[g.L]); g.o = ld3(sh.LO[g.L]); g.kind = 0; }
+  return g;
+}
+PIH_HD bool is_anc(int L, int X) {   // is the joint of link L on the path from link X to its root (inclusive)?
+  if (X < 0) return false;
+  if (L < ANL) return X < ANL && ((L <= 6 && L <= X) || L == X);
+  return X >= ANL && L <= X;
+}
+PIH_HD real jac_entry(const DofGeom& g, int la, int lb, V3 p, V3 dir) {
+  if (g.kind == 2) return 0;
+  real s = (is_anc(g.L, la) ? (real)1 : (real)0) - (is_anc(g.L, lb) ? (real)1 : (real)0);
+  if (s == 0) return 0;
+  real v = g.kind == 0 ? dot(dir, cross(g.a, p - g.o)) : dot(dir, g.a);
+  return s * v;
+}
+
+// ------------------------------------------------------------------------------------------------ PGS
+#ifdef PIH_HOST_EMUL
+template <class F> inline real wave_sum(Wave&, int n, F f) { real s = 0; for (int i = 0; i < n; i++) s += f(i); return s; }
+#else
+PIH_HD real wave_allsum(real x) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+#endif
+
+// Sequential impulse, Bullet resolveSingleConstraintRowGeneric form; row order: motors, joint limits, then per
+// contact (normal, dir1, dir2).  Returns iterations executed.
+template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P) {
+  const int nc = sh.nc;
+#ifdef PIH_HOST_EMUL
+  real* du = sh.du;
+  for (int d = 0; d < ND; d++) du[d] = 0;
+  DofGeom geo[ND];
+  for (int d = 0; d < ND; d++) geo[d] = dof_geom(sh, d);
+  auto Wrow = [&](int row, int d) -> real {   // contact-row response entry for dof d
+    if (d >= 9) return sh.Wp[row][d - 9];
+    int ar = sh.c_arow[row / 3]; return ar >= 0 ? sh.Wa[3 * ar + row % 3][d] : (real)0;
+  };
+  for (int c = 0; c < nc; c++) { real l = sh.r_lam[3 * c]; if (l != 0) for (int d = 0; d < ND; d++) du[d] += Wrow(3 * c, d) * l; }
+  int it = 0;
+  for (; it < P.iters; it++) {
+    real res2 = 0;
+    for (int m = 0; m < NMOT; m++) {
+      int d = m < 9 ? m : 15 + (m - 9);
+      real dl = sh.m_rhs[m] - du[d] * sh.m_dinv[m], sum = sh.m_lam[m] + dl, lim = sh.m_maximp[m];
+      if (sum < -lim) { dl = -lim - sh.m_lam[m]; sum = -lim; } else if (sum > lim) { dl = lim - sh.m_lam[m]; sum = lim; }
+      sh.m_lam[m] = sum;
+      if (m < 9) for (int k = 0; k < 9; k++) du[k] += sh.Wma[m][k] * dl; else for (int k = 0; k < 29; k++) du[9 + k] += sh.Wmp[m - 9][k] * dl;
+      real rs = dl / sh.m_dinv[m]; if (rs * rs > res2) res2 = rs * rs;
+    }
+    for (int k = 0; k < NLIM; k++) {
+      int L = k >> 1; real sg = (k & 1) ? (real)-1 : (real)1;
+      real dl = sh.l_rhs[k] - sg * du[L] * sh.m_dinv[L], sum = sh.l_lam[k] + dl;
+      if (sum < 0) { dl = -sh.l_lam[k]; sum = 0; }
+      sh.l_lam[k] = sum;
+      for (int j = 0; j < 9; j++) du[j] += sg * sh.Wma[L][j] * dl;
+      real rs = dl / sh.m_dinv[L]; if (rs * rs > res2) res2 = rs * rs;
+    }
+    for (int c = 0; c < nc; c++) {
+      if (sh.c_la[c] < 0) continue;
+      V3 p = ld3(sh.c_p[c]);
+      for (int k = 0; k < 3; k++) {
+        int row = 3 * c + k;
+        real lo = 0, hi = PIH_BIG;
+        if (k > 0) { real tot = sh.r_lam[3 * c]; if (!(tot > 0)) continue; hi = sh.c_mu[c] * tot; lo = -hi; }
+        V3 dir = ld3(sh.r_dir[row]);
+        real jd = 0;
+        for (int d = 0; d < ND; d++) jd += jac_entry(geo[d], sh.c_la[c], sh.c_lb[c], p, dir) * du[d];
+        real dl = sh.r_rhs[row] - jd * sh.r_dinv[row], sum = sh.r_lam[row] + dl;
+        if (sum < lo) { dl = lo - sh.r_lam[row]; sum = lo; } else if (sum > hi) { dl = hi - sh.r_lam[row]; sum = hi; }
+        sh.r_lam[row] = sum;
+        for (int d = 0; d < ND; d++) du[d] += Wrow(row, d) * dl;
+        real rs = dl / sh.r_dinv[row]; if (rs * rs > res2) res2 = rs * rs;
+      }
+    }
+    if (res2 <= P.resid) { it++; break; }
+  }
+  for (int d = 0; d < ND; d++) sh.u[d] += du[d];
+  return it;
+#else
+  w.sync();
+  const int d = w.lane();
+  const DofGeom g = dof_geom(sh, d);
+  const bool armlane = d < 9, pipelane = d >= 9 && d < ND;
+  real du = 0;
+  auto Wrow = [&](int row, int c, int k) -> real {
+    if (pipelane) return sh.Wp[row][d - 9];
+    if (armlane) { int ar = sh.c_arow[c]; return ar >= 0 ? sh.Wa[3 * ar + k][d] : (real)0; }
+    return 0;
+  };
+  for (int c = 0; c < nc; c++) { real l = sh.r_lam[3 * c]; if (l != 0) du += Wrow(3 * c, c, 0) * l; }
+  // row multipliers live one per lane (motor m in lane m, limit k in lane k, contact rows re-read from LDS)
+  real mlam = 0, llam = 0;
+  int it = 0;
+  for (; it < P.iters; it++) {
+    real res2 = 0;
+    for (int m = 0; m < NMOT; m++) {
+      int dm = m < 9 ? m : 15 + (m - 9);
+      real dud = __shfl(du, dm, 64);
+      real di = sh.m_dinv[m], lim = sh.m_maximp[m];
+      real lam = __shfl(mlam, m, 64);
+      real dl = sh.m_rhs[m] - dud * di, sum = lam + dl;
+      if (sum < -lim) { dl = -lim - lam; sum = -lim; } else if (sum > lim) { dl = lim - lam; sum = lim; }
+      if (d == m) mlam = sum;
+      real wv = m < 9 ? (armlane ? sh.Wma[m][d] : (real)0) : (pipelane ? sh.Wmp[m - 9][d - 9] : (real)0);
+      du += wv * dl;
+      real rs = dl / di; res2 = rs * rs > res2 ? rs * rs : res2;
+    }
+    for (int k = 0; k < NLIM; k++) {
+      int L = k >> 1; real sg = (k & 1) ? (real)-1 : (real)1;
+      real dud = __shfl(du, L, 64);
+      real di = sh.m_dinv[L];
+      real lam = __shfl(llam, k, 64);
+      real dl = sh.l_rhs[k] - sg * dud * di, sum = lam + dl;
+      if (sum < 0) { dl = -lam; sum = 0; }
+      if (d == k) llam = sum;
+      du += (armlane ? sg * sh.Wma[L][d] : (real)0) * dl;
+      real rs = dl / di; res2 = rs * rs > res2 ? rs * rs : res2;
+    }
+    for (int c = 0; c < nc; c++) {
+      int la = sh.c_la[c], lb = sh.c_lb[c];
+      if (la < 0) continue;
+      V3 p = ld3(sh.c_p[c]);
+      real mu = sh.c_mu[c];
+      real lamn = sh.r_lam[3 * c];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        int row = 3 * c + k;
+        real lo = 0, hi = PIH_BIG;
+        if (k > 0) { if (!(lamn > 0)) continue; hi = mu * lamn; lo = -hi; }
+        V3 dir = ld3(sh.r_dir[row]);
+        real jd = wave_allsum(jac_entry(g, la, lb, p, dir) * du);
+        real di = sh.r_dinv[row], lam = sh.r_lam[row];
+        real dl = sh.r_rhs[row] - jd * di, sum = lam + dl;
+        if (sum < lo) { dl = lo - lam; sum = lo; } else if (sum > hi) { dl = hi - lam; sum = hi; }
+        if (d == 0) sh.r_lam[row] = sum;
+        if (k == 0) lamn = sum;
+        du += Wrow(row, c, k) * dl;
+        real rs = dl / di; res2 = rs * rs > res2 ? rs * rs : res2;
+      }
+      w.sync();
+    }
+    if (res2 <= P.resid) { it++; break; }
+  }
+  if (d < NMOT) sh.m_lam[d] = mlam;
+  if (d < NLIM) sh.l_lam[d] = llam;
+  if (d < ND) sh.u[d] += du;
+  w.sync();
+  return it;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ full step
+template <class W>
+PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* action, real* obs, real* reward, unsigned char* done, real* dbg) {
+  real* S = sh.S;
+  const real dt = P.dt;
+  bool frozen = !P.autoreset && S[PIH_S_DONE] != 0;   // finished envs keep their last values (envs/base_env.py:62,66)
+  fk_all(w, sh);
+  if (!frozen) {
+    controller(w, sh, P, action);
+    collide(w, sh, P);
+    w.par(ND, [&](int d) {
+      real v;
+      if (d < 9) v = S[PIH_S_QDARM + d]; else if (d < 12) v = S[PIH_S_VLIN + d - 9]; else if (d < 15) v = S[PIH_S_VANG + d - 12]; else v = S[PIH_S_QDJ + d - 15];
+      sh.u[d] = v;
+    });
+    aba(w, sh);
+    w.par(ND, [&](int d) { sh.u[d] += dt * sh.udot[d]; });
+    if (dbg && P.debug) {
+      w.par(ND, [&](int d) { dbg[d] = sh.udot[d]; });
+      w.par(sh.nc, [&](int c) {
+        real* o = dbg + 40 + 12 * c;
+        o[0] = (real)sh.c_la[c]; o[1] = (real)sh.c_lb[c]; o[2] = sh.c_p[c][0]; o[3] = sh.c_p[c][1]; o[4] = sh.c_p[c][2];
+        o[5] = sh.c_n[c][0]; o[6] = sh.c_n[c][1]; o[7] = sh.c_n[c][2]; o[8] = sh.c_depth[c]; o[9] = sh.c_mu[c]; o[10] = (real)sh.c_key[c];
+      });
+    }
+    build_rows(w, sh, P);
+    int iters = pgs(w, sh, P);
+    // integrate + bookkeeping
+    w.par(ND, [&](int d) {
+      real v = sh.u[d];
+      if (d < 9 || d >= 15) v = clampr(v, -PIH_MAX_COORD_VEL, PIH_MAX_COORD_VEL);
+      if (d < 9) { S[PIH_S_QDARM + d] = v; S[PIH_S_QARM + d] += dt * v; }
+      else if (d < 12) { S[PIH_S_VLIN + d - 9] = v; S[PIH_S_POS + d - 9] += dt * v; }
+      else if (d < 15) S[PIH_S_VANG + d - 12] = v;
+      else { S[PIH_S_QDJ + d - 15] = v; S[PIH_S_QJ + d - 15] += dt * v; }
+    });
+    {
+      V3 wv = ld3(S + PIH_S_VANG);
+      real wn = norm(wv), th = wn * dt, sn, cs;
+      sincos_((real)0.5 * th, &sn, &cs);
+      real k = th > (real)1e-12 ? sn / wn : (real)0.5 * dt;
+      Q4 dq; dq.x = wv.x * k; dq.y = wv.y * k; dq.z = wv.z * k; dq.w = cs;
+      Q4 q0; q0.x = S[PIH_S_QUAT]; q0.y = S[PIH_S_QUAT + 1]; q0.z = S[PIH_S_QUAT + 2]; q0.w = S[PIH_S_QUAT + 3];
+      Q4 qn = q_mul(dq, q0);
+      real nn = rsqrt_(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+      S[PIH_S_QUAT] = qn.x * nn; S[PIH_S_QUAT + 1] = qn.y * nn; S[PIH_S_QUAT + 2] = qn.z * nn; S[PIH_S_QUAT + 3] = qn.w * nn;
+    }
+    // warm-start cache + contact normal force (p11)
+    real cf = 0;
+    for (int c = 0; c < sh.nc; c++) if (sh.c_key[c] >= 0 && sh.c_key[c] < 1000) cf += sh.r_lam[3 * c];
+    w.par(CMAX, [&](int c) {
+      bool live = c < sh.nc;
+      S[PIH_S_CACHE_KEY + c] = live ? (real)sh.c_key[c] : (real)-1;
+      S[PIH_S_CACHE_LAMBDA + c] = live ? sh.r_lam[3 * c] : (real)0;
+    });
+    if (dbg && P.debug) {
+      w.par(sh.nc, [&](int c) { dbg[40 + 12 * c + 11] = sh.r_lam[3 * c]; });
+      w.par(3 * sh.nc, [&](int r) { dbg[640 + r] = sh.r_dinv[r]; });
+    }
+    S[PIH_S_CACHE_N] = (real)sh.nc;
+    S[PIH_S_CFORCE] = cf / dt; S[PIH_S_NCONTACT] = (real)sh.nc; S[PIH_S_PGS_ITERS] = (real)iters;
+    S[PIH_S_STEPS] += 1;
+    if (dbg && P.debug) { dbg[38] = (real)sh.nc; dbg[39] = (real)iters; }
+    w.sync();
+    fk_all(w, sh);
+  }
+  // outputs: declared 5-vector obs (envs/peg_in_hole.py:13), reward (:114-117), done
+  V3 eep; M3 eeR; ee_pose(sh, eep, eeR);
+  real tip[7]; tip_pose(sh, tip);
+  V3 dh = mk(tip[0], tip[1], tip[2]) - ld3(HOLE_POS);
+  real rew = norm(dh) < (real)0.05 ? (real)1 : (real)0;
+  for (int i = 0; i < 7; i++) S[PIH_S_TIP + i] = tip[i];
+  bool bad = false;
+  for (int i = 0; i < 86; i++) { real v = S[i]; bad = bad || !(v == v) || absr(v) > (real)1e15; }
+  if (!frozen && P.mode == 0 && (rew > 0 || S[PIH_S_STEPS] >= (real)P.maxsteps)) S[PIH_S_DONE] = 1;
+  obs[0] = S[PIH_S_QARM + 7]; obs[1] = S[PIH_S_QARM + 8];
+  obs[2] = eep.x + S[PIH_S_OFFSET]; obs[3] = eep.y + S[PIH_S_OFFSET + 1]; obs[4] = eep.z + S[PIH_S_OFFSET + 2];
+  *reward = rew; *done = (unsigned char)((S[PIH_S_DONE] != 0 || bad) ? 1 : 0);
+  w.sync();
+  if (bad || (P.autoreset && S[PIH_S_DONE] != 0)) {
+    reset_state(S, P, P.env0 + env);
+    w.sync();
+    fk_all(w, sh);
+    real tp2[7]; tip_pose(sh, tp2);
+    for (int i = 0; i < 7; i++) S[PIH_S_TIP + i] = tp2[i];
+    w.sync();
+  }
+}
+
+}  // namespace pih

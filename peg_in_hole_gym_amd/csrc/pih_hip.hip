@@ -1,0 +1,250 @@
+// pih_hip.hip -- kernels + C ABI (include/pih.h) of the MI355X-native peg-in-hole environment.
+// gfx950 only; one wavefront (64 threads, one workgroup) per env; per-env scratch in LDS (struct pih::Shared).
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o libpih_hip.so pih_hip.hip   (see build.py)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "pih_device.h"
+
+using namespace pih;
+
+// ------------------------------------------------------------------------------------------------ kernels
+// state: float[n][256] (env-major records: the 64 lanes of the env's wave read/write consecutive words, so every
+// access is a fully coalesced 256 B segment).
+__global__ void __launch_bounds__(64) pih_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
+                                                      float* __restrict__ obs, float* __restrict__ reward,
+                                                      unsigned char* __restrict__ done, float* __restrict__ dbg) {
+  __shared__ Shared sh;
+  const int env = blockIdx.x, lane = threadIdx.x;
+  Wave w; w.l = lane; w.counter = 0;
+  float* rec = state + (size_t)env * PIH_STATE_WORDS;
+#pragma unroll
+  for (int i = 0; i < PIH_STATE_WORDS / 64; i++) sh.S[lane + 64 * i] = rec[lane + 64 * i];
+  __syncthreads();
+  float a[4] = {0, 0, 0, 0};
+  if (actions) { a[0] = actions[env * 4]; a[1] = actions[env * 4 + 1]; a[2] = actions[env * 4 + 2]; a[3] = actions[env * 4 + 3]; }
+  float o[5], r; unsigned char d;
+  step_env(w, sh, P, env, a, o, &r, &d, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PIH_STATE_WORDS / 64; i++) rec[lane + 64 * i] = sh.S[lane + 64 * i];
+  if (lane < 5 && obs) obs[env * 5 + lane] = o[0] * (lane == 0) + o[1] * (lane == 1) + o[2] * (lane == 2) + o[3] * (lane == 3) + o[4] * (lane == 4);
+  if (lane == 0) { if (reward) reward[env] = r; if (done) done[env] = d; }
+}
+
+__global__ void __launch_bounds__(64) pih_reset_kernel(Params P, float* __restrict__ state, const unsigned char* __restrict__ mask) {
+  __shared__ Shared sh;
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (mask && !mask[env]) return;
+  Wave w; w.l = lane; w.counter = 0;
+  float* rec = state + (size_t)env * PIH_STATE_WORDS;
+  for (int i = 0; i < PIH_STATE_WORDS / 64; i++) sh.S[lane + 64 * i] = rec[lane + 64 * i];
+  __syncthreads();
+  reset_state(sh.S, P, P.env0 + env);
+  __syncthreads();
+  fk_all(w, sh);
+  float tip[7]; tip_pose(sh, tip);
+  for (int i = 0; i < 7; i++) sh.S[PIH_S_TIP + i] = tip[i];
+  __syncthreads();
+  for (int i = 0; i < PIH_STATE_WORDS / 64; i++) rec[lane + 64 * i] = sh.S[lane + 64 * i];
+}
+
+__global__ void __launch_bounds__(64) pih_init_offsets_kernel(float* __restrict__ state, const float* __restrict__ offsets, int n) {
+  int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= n) return;
+  float* rec = state + (size_t)e * PIH_STATE_WORDS;
+  for (int k = 0; k < 3; k++) rec[PIH_S_OFFSET + k] = offsets ? offsets[3 * e + k] : 0.f;
+}
+
+__global__ void __launch_bounds__(64) pih_ik_kernel(Params P, const float* __restrict__ q0, const float* __restrict__ tpos,
+                                                    const float* __restrict__ tquat, float* __restrict__ qout) {
+  __shared__ Shared sh;
+  const int i = blockIdx.x, lane = threadIdx.x;
+  Wave w; w.l = lane; w.counter = 0;
+  float q[9];
+  for (int k = 0; k < 9; k++) q[k] = q0[i * 9 + k];
+  Q4 tq; tq.x = tquat[4 * i]; tq.y = tquat[4 * i + 1]; tq.z = tquat[4 * i + 2]; tq.w = tquat[4 * i + 3];
+  float qs[7];
+  ik_solve(w, sh, P, q, mk(tpos[3 * i], tpos[3 * i + 1], tpos[3 * i + 2]), tq, qs);
+  if (lane < 9) {
+    float v = q[7] * (lane == 7) + q[8] * (lane == 8);
+    for (int k = 0; k < 7; k++) v += qs[k] * (lane == k);
+    qout[i * 9 + lane] = v;
+  }
+}
+
+__global__ void pih_gather_kernel(const float* __restrict__ state, float* __restrict__ out, int n, int word0, int nwords) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * nwords) return;
+  int e = idx / nwords, k = idx - e * nwords;
+  out[idx] = state[(size_t)e * PIH_STATE_WORDS + word0 + k];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct pih_handle {
+  pih_config cfg;
+  Params P;
+  int device;
+  float* state = nullptr;
+  float* dbg = nullptr;
+  std::string err;
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // event pairs bracketing each step launch
+  size_t ev_used = 0;
+};
+
+static thread_local std::string g_err;
+
+static int fail(pih_handle* h, const char* what, hipError_t e) {
+  std::string m = std::string(what) + ": " + hipGetErrorString(e);
+  if (h) h->err = m;
+  g_err = m;
+  return -1;
+}
+#define HIPCHK(h, x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(h, #x, _e); } while (0)
+
+static Params make_params(const pih_config* c) {
+  Params P;
+  P.dt = c->dt; P.resid = c->residual_threshold; P.erp = c->erp; P.warm = c->warmstart; P.margin = c->contact_margin;
+  P.slop = c->linear_slop; P.ikdamp = c->ik_damping; P.ikres = c->ik_residual; P.dv = c->dv; P.iters = c->solver_iters;
+  P.ikiters = c->ik_iters; P.mode = c->mode; P.maxsteps = c->max_episode_steps; P.autoreset = c->auto_reset;
+  P.selfcol = c->enable_self_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed;
+  return P;
+}
+
+extern "C" {
+
+void pih_default_config(pih_config* c) {
+  memset(c, 0, sizeof *c);
+  c->n_envs = 1; c->env_index0 = 0; c->mode = 0; c->solver_iters = 50; c->ik_iters = 20; c->max_episode_steps = 2227;
+  c->auto_reset = 0; c->enable_self_collision = 1; c->debug = 0; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
+  c->erp = 0.2f; c->warmstart = 0.85f; c->contact_margin = 0.005f; c->linear_slop = 1e-5f; c->ik_damping = 0.5f; c->ik_residual = 1e-4f;
+  c->dv = 2.0f / 240.0f;
+}
+int pih_abi_version(void) { return PIH_ABI_VERSION; }
+
+int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** out) {
+  if (!cfg || !out || cfg->n_envs <= 0) { g_err = "pih_create: bad arguments"; return -2; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) { g_err = "pih_create: no HIP device (this library has no CPU path)"; return -3; }
+  pih_handle* h = new pih_handle;
+  h->cfg = *cfg; h->P = make_params(cfg);
+  HIPCHK(h, hipGetDevice(&h->device));
+  size_t nb = (size_t)cfg->n_envs * PIH_STATE_WORDS * sizeof(float);
+  HIPCHK(h, hipMalloc(&h->state, nb));
+  HIPCHK(h, hipMemset(h->state, 0, nb));
+  if (cfg->debug) { HIPCHK(h, hipMalloc(&h->dbg, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); HIPCHK(h, hipMemset(h->dbg, 0, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); }
+  float* offd = nullptr;
+  if (offsets_host) {
+    HIPCHK(h, hipMalloc(&offd, (size_t)cfg->n_envs * 3 * sizeof(float)));
+    HIPCHK(h, hipMemcpy(offd, offsets_host, (size_t)cfg->n_envs * 3 * sizeof(float), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(pih_init_offsets_kernel, dim3((cfg->n_envs + 63) / 64), dim3(64), 0, 0, h->state, offd, cfg->n_envs);
+  hipLaunchKernelGGL(pih_reset_kernel, dim3(cfg->n_envs), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipDeviceSynchronize());
+  if (offd) hipFree(offd);
+  *out = h;
+  return 0;
+}
+
+int pih_destroy(pih_handle* h) {
+  if (!h) return 0;
+  for (auto& p : h->ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  if (h->state) hipFree(h->state);
+  if (h->dbg) hipFree(h->dbg);
+  delete h;
+  return 0;
+}
+
+int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, void* stream) {
+  (void)hard;   // the reference reloads every URDF on reset regardless (envs/peg_in_hole.py:227-251)
+  if (!h) return -2;
+  hipLaunchKernelGGL(pih_reset_kernel, dim3(h->cfg.n_envs), dim3(64), 0, (hipStream_t)stream, h->P, h->state, mask_dev);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+static int launch_step(pih_handle* h, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t s) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->timing) {
+    if (h->ev_used == h->ev.size()) {
+      hipEvent_t a, b;
+      HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
+      h->ev.emplace_back(a, b);
+    }
+    e0 = h->ev[h->ev_used].first; e1 = h->ev[h->ev_used].second; h->ev_used++;
+    HIPCHK(h, hipEventRecord(e0, s));
+  }
+  hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, actions, obs, reward, done, h->dbg);
+  if (h->timing) HIPCHK(h, hipEventRecord(e1, s));
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int pih_step(pih_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
+  if (!h) return -2;
+  if (h->cfg.mode == 0 && !actions_dev) { h->err = "pih_step: actions_dev is NULL in action mode"; return -2; }
+  return launch_step(h, actions_dev, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
+}
+
+int pih_step_n(pih_handle* h, int k, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
+  if (!h || k < 0) return -2;
+  if (h->cfg.mode == 0 && !actions_dev) { h->err = "pih_step_n: actions_dev is NULL in action mode"; return -2; }
+  for (int i = 0; i < k; i++) { int r = launch_step(h, actions_dev, obs_dev, reward_dev, done_dev, (hipStream_t)stream); if (r) return r; }
+  return 0;
+}
+
+int pih_get_state(pih_handle* h, int field, void* out_dev, void* stream) {
+  if (!h || !out_dev) return -2;
+  hipStream_t s = (hipStream_t)stream;
+  const int n = h->cfg.n_envs;
+  switch (field) {
+    case PIH_FIELD_STATE: HIPCHK(h, hipMemcpyAsync(out_dev, h->state, (size_t)n * PIH_STATE_WORDS * sizeof(float), hipMemcpyDeviceToDevice, s)); return 0;
+    case PIH_FIELD_TIP_POSE: hipLaunchKernelGGL(pih_gather_kernel, dim3((n * 7 + 255) / 256), dim3(256), 0, s, h->state, (float*)out_dev, n, (int)PIH_S_TIP, 7); break;
+    case PIH_FIELD_CONTACT_FORCE: hipLaunchKernelGGL(pih_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->state, (float*)out_dev, n, (int)PIH_S_CFORCE, 1); break;
+    case PIH_FIELD_DEBUG:
+      if (!h->dbg) { h->err = "pih_get_state: debug buffer not enabled (config.debug = 0)"; return -4; }
+      HIPCHK(h, hipMemcpyAsync(out_dev, h->dbg, (size_t)n * PIH_DEBUG_WORDS * sizeof(float), hipMemcpyDeviceToDevice, s)); return 0;
+    default: h->err = "pih_get_state: unknown field"; return -2;
+  }
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int pih_set_state(pih_handle* h, int field, const void* in_dev, void* stream) {
+  if (!h || !in_dev) return -2;
+  if (field != PIH_FIELD_STATE) { h->err = "pih_set_state: only PIH_FIELD_STATE is writable"; return -2; }
+  HIPCHK(h, hipMemcpyAsync(h->state, in_dev, (size_t)h->cfg.n_envs * PIH_STATE_WORDS * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream) {
+  if (!h || n <= 0 || !q0_dev || !tpos_dev || !tquat_dev || !qout_dev) return -2;
+  hipLaunchKernelGGL(pih_ik_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, h->P, q0_dev, tpos_dev, tquat_dev, qout_dev);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int pih_set_timing(pih_handle* h, int enable) { if (!h) return -2; h->timing = enable != 0; return 0; }
+
+int pih_timing(pih_handle* h, int reset, double* avg_ms_out, int64_t* launches_out) {
+  if (!h) return -2;
+  double tot = 0;
+  for (size_t i = 0; i < h->ev_used; i++) {
+    HIPCHK(h, hipEventSynchronize(h->ev[i].second));
+    float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i].first, h->ev[i].second));
+    tot += ms;
+  }
+  if (avg_ms_out) *avg_ms_out = h->ev_used ? tot / (double)h->ev_used : 0.0;
+  if (launches_out) *launches_out = (int64_t)h->ev_used;
+  if (reset) h->ev_used = 0;
+  return 0;
+}
+
+const char* pih_last_error(pih_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+}  // extern "C"

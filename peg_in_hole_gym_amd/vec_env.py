@@ -1,0 +1,123 @@
+"""Tensor-level vectorised environment: thin host wrapper over the C ABI (include/pih.h).
+
+All data stay on the GPU as PyTorch-ROCm tensors; PyTorch is only the owner of device memory and of the stream."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class PihVecEnv:
+    """N independent Panda + pipe + hole worlds on one MI355X, one wavefront per world.
+
+    step(actions[N,4]) -> obs[N,5] (finger1, finger2, ee xyz; envs/peg_in_hole.py:13), reward[N], done[N]
+    mirrors BaseEnv.step (envs/base_env.py:60-75) for every agent at once; see include/pih.h for what each call replaces.
+    """
+
+    def __init__(self, n_envs, device="cuda:0", offsets=None, **cfg):
+        if not torch.cuda.is_available():
+            raise _lib.PihError("no ROCm device visible: peg_in_hole_gym_amd has no CPU path")
+        self.L = _lib.load()
+        self.n = int(n_envs)
+        self.device = torch.device(device)
+        self.cfg = _lib.default_config(n_envs=self.n, **cfg)
+        off = None
+        if offsets is not None:
+            off = np.ascontiguousarray(np.asarray(offsets, dtype=np.float32).reshape(self.n, 3))
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.L.pih_create(C.byref(self.cfg), off.ctypes.data if off is not None else None, C.byref(self.h))
+        if rc != 0:
+            raise _lib.PihError("pih_create failed (%d): %s" % (rc, self.L.pih_last_error(None).decode()))
+        self.obs = torch.zeros(self.n, _lib.OBS_DIM, device=self.device)
+        self.reward = torch.zeros(self.n, device=self.device)
+        self.done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.pih_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise _lib.PihError("%s failed (%d): %s" % (what, rc, self.L.pih_last_error(self.h).decode()))
+
+    def reset(self, mask=None, hard_reset=False):
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            self._chk(self.L.pih_reset(self.h, m.data_ptr() if m is not None else None, int(hard_reset), self._stream()), "pih_reset")
+
+    def step(self, actions):
+        a = None
+        if actions is not None:
+            a = actions.to(device=self.device, dtype=torch.float32).contiguous()
+            assert a.shape == (self.n, _lib.ACTION_DIM), a.shape
+        with torch.cuda.device(self.device):
+            self._chk(self.L.pih_step(self.h, a.data_ptr() if a is not None else None, self.obs.data_ptr(), self.reward.data_ptr(),
+                                      self.done.data_ptr(), self._stream()), "pih_step")
+        return self.obs, self.reward, self.done
+
+    def step_n(self, k, actions=None):
+        a = None
+        if actions is not None:
+            a = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            self._chk(self.L.pih_step_n(self.h, int(k), a.data_ptr() if a is not None else None, self.obs.data_ptr(),
+                                        self.reward.data_ptr(), self.done.data_ptr(), self._stream()), "pih_step_n")
+        return self.obs, self.reward, self.done
+
+    def _get(self, field, shape):
+        out = torch.empty(shape, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._chk(self.L.pih_get_state(self.h, field, out.data_ptr(), self._stream()), "pih_get_state")
+        return out
+
+    def state(self):
+        return self._get(_lib.FIELD_STATE, (self.n, _lib.STATE_WORDS))
+
+    def set_state(self, s):
+        s = s.to(device=self.device, dtype=torch.float32).contiguous()
+        assert s.shape == (self.n, _lib.STATE_WORDS)
+        with torch.cuda.device(self.device):
+            self._chk(self.L.pih_set_state(self.h, _lib.FIELD_STATE, s.data_ptr(), self._stream()), "pih_set_state")
+
+    def tip_pose(self):
+        return self._get(_lib.FIELD_TIP_POSE, (self.n, 7))
+
+    def contact_force(self):
+        return self._get(_lib.FIELD_CONTACT_FORCE, (self.n,))
+
+    def debug(self):
+        return self._get(_lib.FIELD_DEBUG, (self.n, _lib.DEBUG_WORDS))
+
+    def ik(self, q0, tpos, tquat):
+        q0 = q0.to(device=self.device, dtype=torch.float32).contiguous()
+        tpos = tpos.to(device=self.device, dtype=torch.float32).contiguous()
+        tquat = tquat.to(device=self.device, dtype=torch.float32).contiguous()
+        n = q0.shape[0]
+        out = torch.empty(n, 9, device=self.device)
+        with torch.cuda.device(self.device):
+            self._chk(self.L.pih_ik(self.h, n, q0.data_ptr(), tpos.data_ptr(), tquat.data_ptr(), out.data_ptr(), self._stream()), "pih_ik")
+        return out
+
+    def set_timing(self, enable):
+        self.L.pih_set_timing(self.h, int(enable))
+
+    def timing(self, reset=True):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        self._chk(self.L.pih_timing(self.h, int(reset), C.byref(ms), C.byref(n)), "pih_timing")
+        return ms.value, n.value

@@ -1,0 +1,76 @@
+// pih_emul.cpp -- TEST-ONLY host build of the product's per-env step (peg_in_hole_gym_amd/csrc/pih_device.h compiled
+// with PIH_HOST_EMUL: lanes become loops).  It exists so that the device algorithm (ABA + impulse responses + PGS with
+// on-the-fly Jacobians) can be checked against the fp64 oracle in this GPU-less container, in double (algorithmic
+// equivalence) and in float (fp32 sensitivity).  It is NOT part of the product: libpih_hip.so contains no host path.
+#define PIH_HOST_EMUL 1
+#include "../../peg_in_hole_gym_amd/csrc/pih_device.h"
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace pih;
+
+struct Emul {
+  Params P; int n;
+  std::vector<real> state;   // n * 256
+  std::vector<real> dbg;     // n * 1024
+};
+
+static Params make_params(const pih_config* c) {
+  Params P;
+  P.dt = (real)c->dt; P.resid = (real)c->residual_threshold; P.erp = (real)c->erp; P.warm = (real)c->warmstart;
+  P.margin = (real)c->contact_margin; P.slop = (real)c->linear_slop; P.ikdamp = (real)c->ik_damping; P.ikres = (real)c->ik_residual;
+  P.dv = (real)c->dv; P.iters = c->solver_iters; P.ikiters = c->ik_iters; P.mode = c->mode; P.maxsteps = c->max_episode_steps;
+  P.autoreset = c->auto_reset; P.selfcol = c->enable_self_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed;
+  return P;
+}
+
+extern "C" {
+int emul_real_bytes() { return (int)sizeof(real); }
+int emul_shared_bytes() { return (int)sizeof(Shared); }
+// double-precision overrides of the float config fields (so the f64 build is not limited by float dt etc.)
+void* emul_create(const pih_config* c, const double* offsets, double dt) {
+  Emul* e = new Emul;
+  e->P = make_params(c); e->n = c->n_envs;
+  if (dt > 0) e->P.dt = (real)dt;
+  if (c->mode == 0 && c->dv == 0) e->P.dv = (real)(2.0 / 240.0);
+  e->state.assign((size_t)e->n * PIH_STATE_WORDS, 0); e->dbg.assign((size_t)e->n * PIH_DEBUG_WORDS, 0);
+  for (int i = 0; i < e->n; i++) {
+    real* S = &e->state[(size_t)i * PIH_STATE_WORDS];
+    if (offsets) for (int k = 0; k < 3; k++) S[PIH_S_OFFSET + k] = (real)offsets[3 * i + k];
+    reset_state(S, e->P, e->P.env0 + i);
+  }
+  return e;
+}
+void emul_set_dv(void* h, double dv) { ((Emul*)h)->P.dv = (real)dv; }
+void emul_destroy(void* h) { delete (Emul*)h; }
+void emul_reset(void* h, const unsigned char* mask) {
+  Emul* e = (Emul*)h;
+  for (int i = 0; i < e->n; i++) if (!mask || mask[i]) reset_state(&e->state[(size_t)i * PIH_STATE_WORDS], e->P, e->P.env0 + i);
+}
+void emul_step(void* h, const double* actions, double* obs, double* reward, unsigned char* done) {
+  Emul* e = (Emul*)h;
+  static Shared sh;
+  for (int i = 0; i < e->n; i++) {
+    real* S = &e->state[(size_t)i * PIH_STATE_WORDS];
+    memcpy(sh.S, S, sizeof(real) * PIH_STATE_WORDS);
+    real a[4], o[5], r; unsigned char d;
+    for (int k = 0; k < 4; k++) a[k] = (real)actions[4 * i + k];
+    Wave w;
+    step_env(w, sh, e->P, i, a, o, &r, &d, &e->dbg[(size_t)i * PIH_DEBUG_WORDS]);
+    memcpy(S, sh.S, sizeof(real) * PIH_STATE_WORDS);
+    for (int k = 0; k < 5; k++) obs[5 * i + k] = o[k];
+    reward[i] = r; done[i] = d;
+  }
+}
+void emul_get_state(void* h, double* out) { Emul* e = (Emul*)h; for (size_t i = 0; i < e->state.size(); i++) out[i] = e->state[i]; }
+void emul_set_state(void* h, const double* in) { Emul* e = (Emul*)h; for (size_t i = 0; i < e->state.size(); i++) e->state[i] = (real)in[i]; }
+void emul_get_debug(void* h, double* out) { Emul* e = (Emul*)h; for (size_t i = 0; i < e->dbg.size(); i++) out[i] = e->dbg[i]; }
+void emul_ik(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout) {
+  static Shared sh; Params P = make_params(c); Wave w;
+  real q[9], qo[7]; for (int i = 0; i < 9; i++) q[i] = (real)q0[i];
+  Q4 tq; tq.x = (real)tquat[0]; tq.y = (real)tquat[1]; tq.z = (real)tquat[2]; tq.w = (real)tquat[3];
+  ik_solve(w, sh, P, q, mk((real)tpos[0], (real)tpos[1], (real)tpos[2]), tq, qo);
+  for (int i = 0; i < 7; i++) qout[i] = qo[i]; qout[7] = q0[7]; qout[8] = q0[8];
+}
+}

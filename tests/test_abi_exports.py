@@ -1,0 +1,42 @@
+"""The C-ABI library loads and exports every symbol include/pih.h declares (no compute: no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported():
+    import __graft_entry__ as ge
+    ge.build()
+    hdr = open(os.path.join(ROOT, "include", "pih.h")).read()
+    names = sorted(set(re.findall(r"\b(pih_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 12
+    L = ctypes.CDLL(os.path.join(ROOT, "peg_in_hole_gym_amd", "csrc", "libpih_hip.so"))
+    for n in names:
+        assert hasattr(L, n), n
+    from peg_in_hole_gym_amd import _lib
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_config_struct_layout_matches_header():
+    from peg_in_hole_gym_amd import _lib
+    assert ctypes.sizeof(_lib.PihConfig) == 10 * 4 + 8 + 12 * 4
+    c = _lib.default_config()
+    assert c.solver_iters == 50 and c.ik_iters == 20 and abs(c.dt - 1 / 240) < 1e-9 and c.max_episode_steps == 2227
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return
+    from peg_in_hole_gym_amd import _lib
+    L = _lib.load()
+    c = _lib.default_config(n_envs=4)
+    h = ctypes.c_void_p()
+    assert L.pih_create(ctypes.byref(c), None, ctypes.byref(h)) != 0
+    assert b"no HIP device" in L.pih_last_error(None)
+    import pytest
+    from peg_in_hole_gym_amd.vec_env import PihVecEnv
+    with pytest.raises(_lib.PihError):
+        PihVecEnv(4)
