@@ -36,7 +36,8 @@ enum {
   PIH_S_QARM = 0, PIH_S_QDARM = 9, PIH_S_POS = 18, PIH_S_QUAT = 21, PIH_S_VLIN = 25, PIH_S_VANG = 28,
   PIH_S_QJ = 31, PIH_S_QDJ = 54, PIH_S_TARGET = 77,
   PIH_S_FSM = 86, PIH_S_FSMT = 87, PIH_S_DONE = 88, PIH_S_GRASP = 89, PIH_S_RANDY = 90, PIH_S_ATTACH = 91,
-  PIH_S_RNG = 92, PIH_S_STEPS = 93, PIH_S_OFFSET = 94, PIH_S_SPARE = 97,
+  PIH_S_RNG = 92, PIH_S_STEPS = 93, PIH_S_OFFSET = 94,
+  PIH_S_SPARE = 97,        /* number of times this env was reset because its state became non-finite */
   PIH_S_TIP = 98,          /* peg-tip pose xyz + quat(xyzw) after the last step (7) */
   PIH_S_CFORCE = 105,      /* sum of contact normal impulses / dt of the last step [N] */
   PIH_S_NCONTACT = 106,

@@ -15,7 +15,8 @@
  * Dynamics algorithm (deliberately different from the product's ABA so the parity test compares two
  * independent derivations): world-frame recursive Newton-Euler (RNEA) gives the bias force and, column by
  * column, the joint-space mass matrix; dense Cholesky gives M^-1; constraint rows are solved with Bullet's
- * sequential-impulse PGS in velocity space (row order: motors, joint limits, then per contact normal/dir1/dir2).
+ * sequential-impulse PGS in velocity space (row order: per arm joint motor/lower/upper limit, the 23 pipe
+ * motors, then per contact normal/dir1/dir2).
  */
 #include "pih_oracle.h"
 #include "../include/pih_model.h"
@@ -441,11 +442,12 @@ static void tip_pose(const Env* E, const LinkKin* K, double* out) {
 static void reset_env(piho_handle* h, int e) {
   Env* E = &h->env[e];
   double* s = E->s;
-  double off[3] = {s[PIHO_S_OFFSET], s[PIHO_S_OFFSET + 1], s[PIHO_S_OFFSET + 2]};
+  double off[3] = {s[PIHO_S_OFFSET], s[PIHO_S_OFFSET + 1], s[PIHO_S_OFFSET + 2]}, nbad = s[PIHO_S_SPARE];
   uint64_t ctr = (uint64_t)s[PIHO_S_RNG];
   uint64_t seed = h->cfg.seed + 1000ULL + (uint64_t)e;
   memset(s, 0, sizeof(double) * PIHO_STATE_WORDS);
   for (int k = 0; k < 3; k++) s[PIHO_S_OFFSET + k] = off[k];
+  s[PIHO_S_SPARE] = nbad;
   for (int i = 0; i < 9; i++) { s[PIHO_S_QARM + i] = ARM_REST[i]; s[PIHO_S_TARGET + i] = ARM_REST[i]; }
   const double U = 1.0 / 16777216.0;
   s[PIHO_S_POS] = -0.2 + 0.4 * (rng24(seed, ctr++) * U);      /* uniform(-0.2, 0.2)   :239 */
@@ -688,7 +690,7 @@ static void step_env(piho_handle* h, int e, const double* action, double* obs, d
   /* ---- constraint rows: motors, joint limits, contact normals, contact frictions */
   int nr = 0;
   double col[ND];
-  for (int m = 0; m < 32; m++) {
+  for (int m = 0; m < 32; m++) {          /* arm joint m < 9: motor, lower limit, upper limit; then the 23 pipe motors */
     int d = m < 9 ? m : 15 + (m - 9);
     Row* r = &rows[nr++];
     memset(r, 0, sizeof *r);
@@ -699,19 +701,19 @@ static void step_env(piho_handle* h, int e, const double* action, double* obs, d
     /* btMultiBodyJointMotor: desired velocity = kp (q* - q)/dt + qd + kd (0 - qd), kd = 1 */
     double vt = mt_posctl[m] ? mt_kp[m] * (mt_target[m] - qcur) / dt : 0.0;
     r->rhs = (vt - u[d]) * r->dinv; r->lo = -mt_maximp[m]; r->hi = mt_maximp[m]; r->fparent = -1;
-  }
-  for (int L = 0; L < ANL; L++) {
-    if (!L_LIMITED[L]) continue;
-    for (int side = 0; side < 2; side++) {
-      Row* r = &rows[nr++];
-      memset(r, 0, sizeof *r);
-      double sg = side == 0 ? 1.0 : -1.0;
-      r->J[L] = sg;
-      for (int i = 0; i < ND; i++) r->W[i] = sg * rows[L].W[i];
-      r->dinv = rows[L].dinv;
-      double pen = side == 0 ? s[PIHO_S_QARM + L] - L_LO[L] : L_HI[L] - s[PIHO_S_QARM + L];
-      double vb = pen > 0 ? -pen / dt : -c->erp * pen / dt;
-      r->rhs = (vb - sg * u[L]) * r->dinv; r->lo = 0; r->hi = 1e30; r->fparent = -1;
+    if (m < 9 && L_LIMITED[m]) {
+      const Row* mr = r;
+      for (int side = 0; side < 2; side++) {
+        Row* q = &rows[nr++];
+        memset(q, 0, sizeof *q);
+        double sg = side == 0 ? 1.0 : -1.0;
+        q->J[m] = sg;
+        for (int i = 0; i < ND; i++) q->W[i] = sg * mr->W[i];
+        q->dinv = mr->dinv;
+        double pen = side == 0 ? s[PIHO_S_QARM + m] - L_LO[m] : L_HI[m] - s[PIHO_S_QARM + m];
+        double vb = pen > 0 ? -pen / dt : -c->erp * pen / dt;
+        q->rhs = (vb - sg * u[m]) * q->dinv; q->lo = 0; q->hi = 1e30; q->fparent = -1;
+      }
     }
   }
   int row_n0 = nr, nc = E->ncontacts;
@@ -793,6 +795,7 @@ static void step_env(piho_handle* h, int e, const double* action, double* obs, d
   obs[0] = s[PIHO_S_QARM + 7]; obs[1] = s[PIHO_S_QARM + 8];
   for (int k = 0; k < 3; k++) obs[2 + k] = eep[k] + s[PIHO_S_OFFSET + k];
   *reward = rew; *done = (uint8_t)(s[PIHO_S_DONE] != 0 || bad);
+  if (bad) { if (!isfinite(s[PIHO_S_RNG])) s[PIHO_S_RNG] = 0; s[PIHO_S_SPARE] = (isfinite(s[PIHO_S_SPARE]) ? s[PIHO_S_SPARE] : 0) + 1; }
   if (bad || (c->auto_reset && s[PIHO_S_DONE] != 0)) reset_env(h, e);
 }
 

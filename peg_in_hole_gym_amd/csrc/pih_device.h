@@ -67,6 +67,15 @@ PIH_CONST real FSM_DUR[10] = {0.25, 2, 2, 1, 1.5, 1.5, 0.5, 0.25, 0.25, 0.25};  
 #define PIH_MAX_FRICTION ((real)10)
 #define PIH_BIG ((real)1e30)
 
+// Accumulator type of the articulated-inertia sweep.  Measured (tests/emul, f32 vs f32a builds): keeping this sweep in
+// fp64 halves the fp32 error of the free acceleration (1e-5 -> 5e-6 relative) but leaves the one-step pose / contact-force
+// error percentiles unchanged (those are dominated by PGS on the mu = 10 tip contacts), so the product uses `real`.
+#ifdef PIH_AREAL
+typedef PIH_AREAL areal;
+#else
+typedef real areal;
+#endif
+
 struct Params {
   real dt, resid, erp, warm, margin, slop, ikdamp, ikres, dv;
   int iters, ikiters, mode, maxsteps, autoreset, selfcol, debug, env0;
@@ -81,7 +90,7 @@ struct Shared {
   real Tl[NL][12];                 // local (parent->link) transforms
   real LR[NL][9], LO[NL][3], LA[NL][3], LRC[NL][3], LIC[NL][6];   // world pose, joint axis, com offset, inertia
   real VW[NL][3], VV[NL][3];       // link angular velocity, velocity of the link-origin point
-  real IA[NL][21], PA[NL][6];      // articulated inertia (A6 B9 C6) / bias force accumulators
+  areal IA[NL][21], PA[NL][6];     // articulated inertia (A6 B9 C6) / bias force accumulators
   real CB[NL][6];                  // velocity-product accelerations
   real AU[NL][6], ADinv[NL], Au[NL], AR[NL][3];   // U = I^A S, 1/D, u, r = o_L - o_parent
   real Inv6[36];
@@ -90,7 +99,8 @@ struct Shared {
   int c_la[CMAX], c_lb[CMAX], c_key[CMAX], c_arow[CMAX];
   real c_p[CMAX][3], c_n[CMAX][3], c_depth[CMAX], c_mu[CMAX];
   int nc, nca;
-  real r_dir[NROWC][3], r_dinv[NROWC], r_rhs[NROWC], r_lam[NROWC];
+  real r_dir[NROWC][3], r_dinv[NROWC], r_rhs[NROWC], r_lam[NROWC], r_dvp[NROWC][3];
+  real crec[CMAX][32];            // packed per-contact solver record (see pack_contacts)
   real Wp[NROWC][WPS];
   real Wa[3 * CAMAX][9];
   real m_vt[NMOT], m_maximp[NMOT], m_dinv[NMOT], m_rhs[NMOT], m_lam[NMOT];
@@ -278,11 +288,11 @@ template <class W> PIH_HD void ik_solve(W& w, Shared& sh, const Params& P, const
 // ------------------------------------------------------------------------------------------------ reset
 // envs/peg_in_hole.py:227-274 with the RNG draw order of SURVEY.md App. E (own counter RNG).  Wave-uniform.
 PIH_HD void reset_state(real* S, const Params& P, int env_global) {
-  real off0 = S[PIH_S_OFFSET], off1 = S[PIH_S_OFFSET + 1], off2 = S[PIH_S_OFFSET + 2];
+  real off0 = S[PIH_S_OFFSET], off1 = S[PIH_S_OFFSET + 1], off2 = S[PIH_S_OFFSET + 2], nbad = S[PIH_S_SPARE];
   uint64_t ctr = (uint64_t)S[PIH_S_RNG];
   uint64_t seed = P.seed + 1000ULL + (uint64_t)env_global;
   for (int i = 0; i < PIH_STATE_WORDS; i++) S[i] = 0;
-  S[PIH_S_OFFSET] = off0; S[PIH_S_OFFSET + 1] = off1; S[PIH_S_OFFSET + 2] = off2;
+  S[PIH_S_OFFSET] = off0; S[PIH_S_OFFSET + 1] = off1; S[PIH_S_OFFSET + 2] = off2; S[PIH_S_SPARE] = nbad;
   for (int i = 0; i < 9; i++) { S[PIH_S_QARM + i] = ARM_REST[i]; S[PIH_S_TARGET + i] = ARM_REST[i]; }
   const real U = (real)(1.0 / 16777216.0);
   S[PIH_S_POS] = (real)-0.2 + (real)0.4 * ((real)rng24(seed, ctr++) * U);
@@ -526,7 +536,7 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
     V3 rc = ld3(sh.LRC[L]); S3 Ic = lds3(sh.LIC[L]);
     V3 wv = ld3(sh.VW[L]), vv = ld3(sh.VV[L]);
     // A = Ic + m (|rc|^2 1 - rc rc^T), B = m [rc]x, C = m 1
-    real* I = sh.IA[L];
+    areal* I = sh.IA[L];
     real r2 = dot(rc, rc);
     I[0] = Ic.xx + m * (r2 - rc.x * rc.x); I[1] = Ic.yy + m * (r2 - rc.y * rc.y); I[2] = Ic.zz + m * (r2 - rc.z * rc.z);
     I[3] = Ic.xy - m * rc.x * rc.y; I[4] = Ic.xz - m * rc.x * rc.z; I[5] = Ic.yz - m * rc.y * rc.z;
@@ -548,78 +558,89 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
     real sv = PIH_LIN_DAMP + PIH_LIN_DAMP * norm(vc), sw = PIH_ANG_DAMP + PIH_ANG_DAMP * norm(wv);
     V3 f = m * cross(wv, wrc) - mk(0, 0, m * (real)PIH_GRAVITY_Z) + (m * sv) * vc;
     V3 n = cross(wv, Iw) + sw * Iw + cross(rc, f);
-    st3(sh.PA[L], n); st3(sh.PA[L] + 3, f);
+    sh.PA[L][0] = n.x; sh.PA[L][1] = n.y; sh.PA[L][2] = n.z; sh.PA[L][3] = f.x; sh.PA[L][4] = f.y; sh.PA[L][5] = f.z;
   });
   // inward sweep (wave-uniform)
   for (int L = NL - 1; L >= 0; L--) {
     int p = L_PARENT[L], jt = L_JTYPE[L];
-    const real* I = sh.IA[L];
-    S3 A = lds3(I); M3 B = ldm(I + 6); S3 C = lds3(I + 15);
-    V3 pa = ld3(sh.PA[L]), pl = ld3(sh.PA[L] + 3);
+    const areal* I = sh.IA[L];
+    areal A[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]};
+    areal B[9]; for (int i = 0; i < 9; i++) B[i] = I[6 + i];
+    areal C[9] = {I[15], I[18], I[19], I[18], I[16], I[20], I[19], I[20], I[17]};
+    areal pa[3] = {sh.PA[L][0], sh.PA[L][1], sh.PA[L][2]}, pl[3] = {sh.PA[L][3], sh.PA[L][4], sh.PA[L][5]};
     if (jt == PIH_JT_FLOATING) {
-      // root: invert the 6x6 articulated inertia [[A,B],[B^T,C]] (order: angular, linear) by Gauss-Jordan on SPD
-      real Mx[6][6];
-      M3 Am = s3_to_m(A), Cm = s3_to_m(C);
-      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Mx[i][j] = Am.m[3 * i + j]; Mx[i][3 + j] = B.m[3 * i + j]; Mx[3 + i][j] = B.m[3 * j + i]; Mx[3 + i][3 + j] = Cm.m[3 * i + j]; }
-      real Iv[6][6];
-      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Iv[i][j] = i == j ? (real)1 : (real)0;
+      // root: invert the 6x6 articulated inertia [[A,B],[B^T,C]] (order: angular, linear) by Gauss-Jordan (SPD)
+      areal Mx[6][6], Iv[6][6];
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Mx[i][j] = A[3 * i + j]; Mx[i][3 + j] = B[3 * i + j]; Mx[3 + i][j] = B[3 * j + i]; Mx[3 + i][3 + j] = C[3 * i + j]; }
+      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Iv[i][j] = i == j ? (areal)1 : (areal)0;
 #pragma unroll
       for (int k = 0; k < 6; k++) {
-        real pv = (real)1 / Mx[k][k];
+        areal pv = (areal)1 / Mx[k][k];
 #pragma unroll
         for (int j = 0; j < 6; j++) { Mx[k][j] *= pv; Iv[k][j] *= pv; }
 #pragma unroll
         for (int i = 0; i < 6; i++) if (i != k) {
-          real f = Mx[i][k];
+          areal f = Mx[i][k];
 #pragma unroll
           for (int j = 0; j < 6; j++) { Mx[i][j] -= f * Mx[k][j]; Iv[i][j] -= f * Iv[k][j]; }
         }
       }
-      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.Inv6[6 * i + j] = Iv[i][j];
+      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.Inv6[6 * i + j] = (real)Iv[i][j];
       continue;
     }
-    V3 a = ld3(sh.LA[L]);
-    V3 Ua, Ul; real D, u;
-    real tau = -L_DAMPING[L] * sh.u[link_dof(L)];
-    if (jt == PIH_JT_REVOLUTE) { Ua = mul(A, a); Ul = tmul(B, a); D = dot(a, Ua); u = tau - dot(a, pa); }
-    else { Ua = mul(B, a); Ul = mul(C, a); D = dot(a, Ul); u = tau - dot(a, pl); }
-    real Di = (real)1 / D;
-    st3(sh.AU[L], Ua); st3(sh.AU[L] + 3, Ul); sh.ADinv[L] = Di; sh.Au[L] = u;
+    const areal a[3] = {sh.LA[L][0], sh.LA[L][1], sh.LA[L][2]};
+    areal Ua[3], Ul[3], D, u;
+    areal tau = -(areal)L_DAMPING[L] * (areal)sh.u[link_dof(L)];
+    if (jt == PIH_JT_REVOLUTE) {
+      for (int i = 0; i < 3; i++) { Ua[i] = A[3 * i] * a[0] + A[3 * i + 1] * a[1] + A[3 * i + 2] * a[2]; Ul[i] = B[i] * a[0] + B[3 + i] * a[1] + B[6 + i] * a[2]; }
+      D = a[0] * Ua[0] + a[1] * Ua[1] + a[2] * Ua[2]; u = tau - (a[0] * pa[0] + a[1] * pa[1] + a[2] * pa[2]);
+    } else {
+      for (int i = 0; i < 3; i++) { Ua[i] = B[3 * i] * a[0] + B[3 * i + 1] * a[1] + B[3 * i + 2] * a[2]; Ul[i] = C[3 * i] * a[0] + C[3 * i + 1] * a[1] + C[3 * i + 2] * a[2]; }
+      D = a[0] * Ul[0] + a[1] * Ul[1] + a[2] * Ul[2]; u = tau - (a[0] * pl[0] + a[1] * pl[1] + a[2] * pl[2]);
+    }
+    areal Di = (areal)1 / D;
+    for (int i = 0; i < 3; i++) { sh.AU[L][i] = (real)Ua[i]; sh.AU[L][3 + i] = (real)Ul[i]; }
+    sh.ADinv[L] = (real)Di; sh.Au[L] = (real)u;
     if (p < 0) continue;   // arm root: parent is the fixed world
     // I^a = I^A - U U^T / D
-    sub_outer(A, Ua, Di); sub_outer(C, Ul, Di);
-#pragma unroll
-    for (int i = 0; i < 3; i++) { real ui = i == 0 ? Ua.x : (i == 1 ? Ua.y : Ua.z); B.m[3 * i] -= ui * Ul.x * Di; B.m[3 * i + 1] -= ui * Ul.y * Di; B.m[3 * i + 2] -= ui * Ul.z * Di; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { A[3 * i + j] -= Ua[i] * Ua[j] * Di; B[3 * i + j] -= Ua[i] * Ul[j] * Di; C[3 * i + j] -= Ul[i] * Ul[j] * Di; }
     // p^a = p^A + I^a c + U u / D
-    V3 ca = ld3(sh.CB[L]), cl = ld3(sh.CB[L] + 3);
-    real ud = u * Di;
-    V3 qa = pa + mul(A, ca) + mul(B, cl) + ud * Ua;
-    V3 ql = pl + tmul(B, ca) + mul(C, cl) + ud * Ul;
-    // translate to the parent's origin: r = o_L - o_p
-    V3 r = ld3(sh.AR[L]);
-    M3 Cm = s3_to_m(C);
-    M3 Bt; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Bt.m[3 * i + j] = B.m[3 * j + i];
-    M3 X = skew_mul(r, Bt);              // [r]x B^T
-    M3 Bn = skew_mul(r, Cm);             // [r]x C
-    for (int i = 0; i < 9; i++) Bn.m[i] += B.m[i];   // B' = B + [r]x C
-    M3 Y = mul_skew(Bn, r);              // B' [r]x
-    real* Ip = sh.IA[p];
-    Ip[0] += A.xx + X.m[0] - Y.m[0]; Ip[1] += A.yy + X.m[4] - Y.m[4]; Ip[2] += A.zz + X.m[8] - Y.m[8];
-    Ip[3] += A.xy + (real)0.5 * ((X.m[1] - Y.m[1]) + (X.m[3] - Y.m[3]));
-    Ip[4] += A.xz + (real)0.5 * ((X.m[2] - Y.m[2]) + (X.m[6] - Y.m[6]));
-    Ip[5] += A.yz + (real)0.5 * ((X.m[5] - Y.m[5]) + (X.m[7] - Y.m[7]));
-    for (int i = 0; i < 9; i++) Ip[6 + i] += Bn.m[i];
-    Ip[15] += C.xx; Ip[16] += C.yy; Ip[17] += C.zz; Ip[18] += C.xy; Ip[19] += C.xz; Ip[20] += C.yz;
-    V3 qn = qa + cross(r, ql);
-    real* Pp = sh.PA[p];
-    Pp[0] += qn.x; Pp[1] += qn.y; Pp[2] += qn.z; Pp[3] += ql.x; Pp[4] += ql.y; Pp[5] += ql.z;
+    const areal ca[3] = {sh.CB[L][0], sh.CB[L][1], sh.CB[L][2]}, cl[3] = {sh.CB[L][3], sh.CB[L][4], sh.CB[L][5]};
+    areal ud = u * Di, qa[3], ql[3];
+    for (int i = 0; i < 3; i++) {
+      qa[i] = pa[i] + A[3 * i] * ca[0] + A[3 * i + 1] * ca[1] + A[3 * i + 2] * ca[2] + B[3 * i] * cl[0] + B[3 * i + 1] * cl[1] + B[3 * i + 2] * cl[2] + ud * Ua[i];
+      ql[i] = pl[i] + B[i] * ca[0] + B[3 + i] * ca[1] + B[6 + i] * ca[2] + C[3 * i] * cl[0] + C[3 * i + 1] * cl[1] + C[3 * i + 2] * cl[2] + ud * Ul[i];
+    }
+    // translate to the parent's origin: r = o_L - o_p ;  B' = B + [r]x C ;  A' = A + [r]x B^T - B' [r]x
+    const areal r[3] = {sh.AR[L][0], sh.AR[L][1], sh.AR[L][2]};
+    areal X[9], Bn[9], Y[9];
+    for (int j = 0; j < 3; j++) {   // columns: [r]x M  => column j = r x M[:,j]
+      areal bx = B[3 * j], by = B[3 * j + 1], bz = B[3 * j + 2];            // column j of B^T = row j of B
+      X[j] = r[1] * bz - r[2] * by; X[3 + j] = r[2] * bx - r[0] * bz; X[6 + j] = r[0] * by - r[1] * bx;
+      areal cx = C[j], cy = C[3 + j], cz = C[6 + j];
+      Bn[j] = B[j] + (r[1] * cz - r[2] * cy); Bn[3 + j] = B[3 + j] + (r[2] * cx - r[0] * cz); Bn[6 + j] = B[6 + j] + (r[0] * cy - r[1] * cx);
+    }
+    for (int i = 0; i < 3; i++) {   // rows: M [r]x => row i = M[i,:] x r
+      areal mx = Bn[3 * i], my = Bn[3 * i + 1], mz = Bn[3 * i + 2];
+      Y[3 * i] = my * r[2] - mz * r[1]; Y[3 * i + 1] = mz * r[0] - mx * r[2]; Y[3 * i + 2] = mx * r[1] - my * r[0];
+    }
+    areal* Ip = sh.IA[p];
+    Ip[0] += A[0] + X[0] - Y[0]; Ip[1] += A[4] + X[4] - Y[4]; Ip[2] += A[8] + X[8] - Y[8];
+    Ip[3] += A[1] + (areal)0.5 * ((X[1] - Y[1]) + (X[3] - Y[3]));
+    Ip[4] += A[2] + (areal)0.5 * ((X[2] - Y[2]) + (X[6] - Y[6]));
+    Ip[5] += A[5] + (areal)0.5 * ((X[5] - Y[5]) + (X[7] - Y[7]));
+    for (int i = 0; i < 9; i++) Ip[6 + i] += Bn[i];
+    Ip[15] += C[0]; Ip[16] += C[4]; Ip[17] += C[8]; Ip[18] += C[1]; Ip[19] += C[2]; Ip[20] += C[5];
+    areal* Pp = sh.PA[p];
+    Pp[0] += qa[0] + (r[1] * ql[2] - r[2] * ql[1]); Pp[1] += qa[1] + (r[2] * ql[0] - r[0] * ql[2]); Pp[2] += qa[2] + (r[0] * ql[1] - r[1] * ql[0]);
+    Pp[3] += ql[0]; Pp[4] += ql[1]; Pp[5] += ql[2];
   }
   // outward sweep: accelerations (wave-uniform).  VW/VV are reused to carry (alpha, acc) of each link.
   for (int L = 0; L < NL; L++) {
     int p = L_PARENT[L], jt = L_JTYPE[L], d = link_dof(L);
     V3 al, ac;
     if (jt == PIH_JT_FLOATING) {
-      real pv[6]; for (int i = 0; i < 6; i++) pv[i] = sh.PA[L][i];
+      real pv[6]; for (int i = 0; i < 6; i++) pv[i] = (real)sh.PA[L][i];
       real x[6];
       for (int i = 0; i < 6; i++) { real s = 0; for (int j = 0; j < 6; j++) s -= sh.Inv6[6 * i + j] * pv[j]; x[i] = s; }
       al = mk(x[0], x[1], x[2]); ac = mk(x[3], x[4], x[5]);
@@ -646,8 +667,8 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
 // (either may be -1), or a unit joint impulse on the joint of link jm.  Writes the arm part (9) and pipe part (29)
 // of W = M^-1 J^T and returns J W (the inverse effective mass of the row).
 struct RowOut { real* wa; real* wp; };
-PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, RowOut out) {
-  real jw = 0;
+PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, RowOut out, V3* dvp_out = nullptr) {
+  real jw = 0; V3 dvp = mk(0, 0, 0);
   bool arm = (la >= 0 && la < ANL) || (lb >= 0 && lb < ANL) || (jm >= 0 && jm < ANL);
   bool obj = (la >= ANL) || (lb >= ANL) || (jm >= ANL);
   if (arm && out.wa) {
@@ -681,8 +702,8 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
       if (JT[L] == 0) { dw[L] = aa + dq * a; dvv[L] = ll; } else { dw[L] = aa; dvv[L] = ll + dq * a; }
       out.wa[L] = dq;
       if (L == jm) jw += dq;
-      if (L == la) jw += dot(dir, dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
-      if (L == lb) jw -= dot(dir, dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
+      if (L == la) dvp = dvp + (dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
+      if (L == lb) dvp = dvp - (dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
     }
   }
   if (obj && out.wp) {
@@ -710,8 +731,8 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
       x[i] = s; }
     V3 dw = mk(x[0], x[1], x[2]), dvv = mk(x[3], x[4], x[5]);
     out.wp[0] = dvv.x; out.wp[1] = dvv.y; out.wp[2] = dvv.z; out.wp[3] = dw.x; out.wp[4] = dw.y; out.wp[5] = dw.z;
-    if (ANL == la) jw += dot(dir, dvv + cross(dw, p - ld3(sh.LO[ANL])));
-    if (ANL == lb) jw -= dot(dir, dvv + cross(dw, p - ld3(sh.LO[ANL])));
+    if (ANL == la) dvp = dvp + (dvv + cross(dw, p - ld3(sh.LO[ANL])));
+    if (ANL == lb) dvp = dvp - (dvv + cross(dw, p - ld3(sh.LO[ANL])));
 #pragma unroll
     for (int j = 1; j < ONL; j++) {
       const int L = ANL + j;
@@ -720,11 +741,12 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
       dw = dw + dq * ld3(sh.LA[L]); dvv = ll;
       out.wp[5 + j] = dq;
       if (L == jm) jw += dq;
-      if (L == la) jw += dot(dir, dvv + cross(dw, p - ld3(sh.LO[L])));
-      if (L == lb) jw -= dot(dir, dvv + cross(dw, p - ld3(sh.LO[L])));
+      if (L == la) dvp = dvp + (dvv + cross(dw, p - ld3(sh.LO[L])));
+      if (L == lb) dvp = dvp - (dvv + cross(dw, p - ld3(sh.LO[L])));
     }
   }
-  return jw;
+  if (dvp_out) *dvp_out = dvp;   // relative velocity change at the contact point per unit impulse along dir
+  return jw + dot(dir, dvp);
 }
 
 PIH_HD V3 point_vel(const Shared& sh, int L, V3 p) { return ld3(sh.VV[L]) + cross(ld3(sh.VW[L]), p - ld3(sh.LO[L])); }
@@ -766,7 +788,9 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P) {
     if (la < 0) { sh.r_dinv[row] = 0; sh.r_rhs[row] = 0; sh.r_lam[row] = 0; for (int i = 0; i < 29; i++) sh.Wp[row][i] = 0; return; }
     int ar = sh.c_arow[c];
     RowOut o; o.wp = sh.Wp[row]; o.wa = ar >= 0 ? sh.Wa[3 * ar + k] : nullptr;
-    real jw = response(sh, la, lb, p, dir, -1, o);
+    V3 dvp;
+    real jw = response(sh, la, lb, p, dir, -1, o, &dvp);
+    st3(sh.r_dvp[row], dvp);
     real di = (real)1 / jw;
     V3 vr = point_vel(sh, la, p);
     if (lb >= 0) vr = vr - point_vel(sh, lb, p);
@@ -780,6 +804,20 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P) {
       for (int i = 0; i < ncache; i++) if (sh.S[PIH_S_CACHE_KEY + i] == key) { lam = P.warm * sh.S[PIH_S_CACHE_LAMBDA + i]; break; }
     } else rhs = -ju * di;
     sh.r_dinv[row] = di; sh.r_rhs[row] = rhs; sh.r_lam[row] = lam;
+  });
+  // pack one solver record per contact (lane = contact): everything the PGS block update needs, 128-bit aligned, plus
+  // the cross terms G[a][b] = J_a W_b^T = dir_a . dvp_b that make the in-block (n, t1, t2) update exact Gauss-Seidel
+  w.par(sh.nc, [&](int c) {
+    real* R = sh.crec[c];
+    R[0] = sh.c_p[c][0]; R[1] = sh.c_p[c][1]; R[2] = sh.c_p[c][2]; R[3] = (real)sh.c_la[c];
+    R[4] = (real)sh.c_lb[c]; R[5] = sh.c_mu[c]; R[6] = (real)sh.c_arow[c]; R[7] = 0;
+    for (int k = 0; k < 3; k++) { R[8 + 4 * k] = sh.r_dir[3 * c + k][0]; R[9 + 4 * k] = sh.r_dir[3 * c + k][1]; R[10 + 4 * k] = sh.r_dir[3 * c + k][2]; R[11 + 4 * k] = sh.r_dinv[3 * c + k]; }
+    R[20] = sh.r_rhs[3 * c]; R[21] = sh.r_rhs[3 * c + 1]; R[22] = sh.r_rhs[3 * c + 2];
+    V3 t1 = ld3(sh.r_dir[3 * c + 1]), t2 = ld3(sh.r_dir[3 * c + 2]);
+    R[23] = dot(t1, ld3(sh.r_dvp[3 * c]));       // G[t1][n]
+    R[24] = dot(t2, ld3(sh.r_dvp[3 * c]));       // G[t2][n]
+    R[25] = dot(t2, ld3(sh.r_dvp[3 * c + 1]));   // G[t2][t1]
+    R[26] = 0; R[27] = 0; R[28] = 0; R[29] = 0; R[30] = 0; R[31] = 0;
   });
 }
 
@@ -810,15 +848,27 @@ PIH_HD real jac_entry(const DofGeom& g, int la, int lb, V3 p, V3 dir) {
 #ifdef PIH_HOST_EMUL
 template <class F> inline real wave_sum(Wave&, int n, F f) { real s = 0; for (int i = 0; i < n; i++) s += f(i); return s; }
 #else
-PIH_HD real wave_allsum(real x) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-  return x;
+PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane must be wave-uniform): v_readlane_b32
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+template <int CTRL> PIH_HD real dpp_add(real x) {   // x + x[dpp-permuted lane]  (v_add_f32_dpp)
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// after this every lane holds the sum over its 16-lane row; three independent reductions interleaved for ILP
+PIH_HD void row16_sum3(real& a, real& b, real& c) {
+  a = dpp_add<0xB1>(a); b = dpp_add<0xB1>(b); c = dpp_add<0xB1>(c);        // quad_perm [1,0,3,2]
+  a = dpp_add<0x4E>(a); b = dpp_add<0x4E>(b); c = dpp_add<0x4E>(c);        // quad_perm [2,3,0,1]
+  a = dpp_add<0x141>(a); b = dpp_add<0x141>(b); c = dpp_add<0x141>(c);     // row_half_mirror
+  a = dpp_add<0x140>(a); b = dpp_add<0x140>(b); c = dpp_add<0x140>(c);     // row_mirror
 }
 #endif
 
-// Sequential impulse, Bullet resolveSingleConstraintRowGeneric form; row order: motors, joint limits, then per
-// contact (normal, dir1, dir2).  Returns iterations executed.
+// Sequential impulse, Bullet resolveSingleConstraintRowGeneric form; row order: per arm joint (motor, lower limit, upper
+// limit), the 23 pipe motors, then per contact (normal, dir1, dir2).  Returns iterations executed.
+// GPU form: one lane per DOF holds its entry of the velocity change `du`; row multipliers live lane-distributed in
+// registers (v_readlane to broadcast); motor response rows are preloaded into registers; the arm and pipe motor chains
+// commute (disjoint DOFs) and are interleaved for ILP; each contact is solved as an exact 3x3 Gauss-Seidel block: three
+// DPP row-reductions in flight at once, then the cross terms G bring dir1/dir2 up to date without touching `du`.
 template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P) {
   const int nc = sh.nc;
 #ifdef PIH_HOST_EMUL
@@ -841,14 +891,14 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P) {
       sh.m_lam[m] = sum;
       if (m < 9) for (int k = 0; k < 9; k++) du[k] += sh.Wma[m][k] * dl; else for (int k = 0; k < 29; k++) du[9 + k] += sh.Wmp[m - 9][k] * dl;
       real rs = dl / sh.m_dinv[m]; if (rs * rs > res2) res2 = rs * rs;
-    }
-    for (int k = 0; k < NLIM; k++) {
-      int L = k >> 1; real sg = (k & 1) ? (real)-1 : (real)1;
-      real dl = sh.l_rhs[k] - sg * du[L] * sh.m_dinv[L], sum = sh.l_lam[k] + dl;
-      if (sum < 0) { dl = -sh.l_lam[k]; sum = 0; }
-      sh.l_lam[k] = sum;
-      for (int j = 0; j < 9; j++) du[j] += sg * sh.Wma[L][j] * dl;
-      real rs = dl / sh.m_dinv[L]; if (rs * rs > res2) res2 = rs * rs;
+      if (m < 9) for (int side = 0; side < 2; side++) {   // the joint's lower / upper limit rows follow its motor row
+        int k = 2 * m + side; real sg = side ? (real)-1 : (real)1;
+        real dl2 = sh.l_rhs[k] - sg * du[m] * sh.m_dinv[m], sum2 = sh.l_lam[k] + dl2;
+        if (sum2 < 0) { dl2 = -sh.l_lam[k]; sum2 = 0; }
+        sh.l_lam[k] = sum2;
+        for (int j = 0; j < 9; j++) du[j] += sg * sh.Wma[m][j] * dl2;
+        real rs2 = dl2 / sh.m_dinv[m]; if (rs2 * rs2 > res2) res2 = rs2 * rs2;
+      }
     }
     for (int c = 0; c < nc; c++) {
       if (sh.c_la[c] < 0) continue;
@@ -876,68 +926,91 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P) {
   const int d = w.lane();
   const DofGeom g = dof_geom(sh, d);
   const bool armlane = d < 9, pipelane = d >= 9 && d < ND;
+  // lane-distributed row state: motor m in lane m (m < 32), limit rows of arm joint j in lane j, contact c in lane c
+  real m_di = d < NMOT ? sh.m_dinv[d] : (real)1, m_rhs = d < NMOT ? sh.m_rhs[d] : (real)0, m_lim = d < NMOT ? sh.m_maximp[d] : (real)0;
+  real m_wjj = (real)1 / m_di, m_lam = 0;
+  real lo_rhs = d < 9 ? sh.l_rhs[2 * d] : (real)0, hi_rhs = d < 9 ? sh.l_rhs[2 * d + 1] : (real)0, lo_lam = 0, hi_lam = 0;
+  real cl0 = d < nc ? sh.r_lam[3 * d] : (real)0, cl1 = 0, cl2 = 0;
+  // motor response rows in registers: arm lanes hold column d of Wma, pipe lanes column d-9 of Wmp
+  real wreg[PIH_OBJ_NJ];
+#pragma unroll
+  for (int j = 0; j < PIH_OBJ_NJ; j++) wreg[j] = armlane ? (j < 9 ? sh.Wma[j][d] : (real)0) : (pipelane ? sh.Wmp[j][d - 9] : (real)0);
   real du = 0;
-  auto Wrow = [&](int row, int c, int k) -> real {
-    if (pipelane) return sh.Wp[row][d - 9];
-    if (armlane) { int ar = sh.c_arow[c]; return ar >= 0 ? sh.Wa[3 * ar + k][d] : (real)0; }
-    return 0;
-  };
-  for (int c = 0; c < nc; c++) { real l = sh.r_lam[3 * c]; if (l != 0) du += Wrow(3 * c, c, 0) * l; }
-  // row multipliers live one per lane (motor m in lane m, limit k in lane k, contact rows re-read from LDS)
-  real mlam = 0, llam = 0;
+  for (int c = 0; c < nc; c++) {   // warm start
+    real l = rdlane(cl0, c);
+    if (l != 0) { int ar = sh.c_arow[c]; du += (pipelane ? sh.Wp[3 * c][d - 9] : (armlane && ar >= 0 ? sh.Wa[3 * ar][d] : (real)0)) * l; }
+  }
   int it = 0;
   for (; it < P.iters; it++) {
     real res2 = 0;
-    for (int m = 0; m < NMOT; m++) {
-      int dm = m < 9 ? m : 15 + (m - 9);
-      real dud = __shfl(du, dm, 64);
-      real di = sh.m_dinv[m], lim = sh.m_maximp[m];
-      real lam = __shfl(mlam, m, 64);
-      real dl = sh.m_rhs[m] - dud * di, sum = lam + dl;
-      if (sum < -lim) { dl = -lim - lam; sum = -lim; } else if (sum > lim) { dl = lim - lam; sum = lim; }
-      if (d == m) mlam = sum;
-      real wv = m < 9 ? (armlane ? sh.Wma[m][d] : (real)0) : (pipelane ? sh.Wmp[m - 9][d - 9] : (real)0);
-      du += wv * dl;
-      real rs = dl / di; res2 = rs * rs > res2 ? rs * rs : res2;
-    }
-    for (int k = 0; k < NLIM; k++) {
-      int L = k >> 1; real sg = (k & 1) ? (real)-1 : (real)1;
-      real dud = __shfl(du, L, 64);
-      real di = sh.m_dinv[L];
-      real lam = __shfl(llam, k, 64);
-      real dl = sh.l_rhs[k] - sg * dud * di, sum = lam + dl;
-      if (sum < 0) { dl = -lam; sum = 0; }
-      if (d == k) llam = sum;
-      du += (armlane ? sg * sh.Wma[L][d] : (real)0) * dl;
-      real rs = dl / di; res2 = rs * rs > res2 ? rs * rs : res2;
+#pragma unroll
+    for (int j = 0; j < PIH_OBJ_NJ; j++) {
+      real tot_a = 0;
+      if (j < 9) {   // arm joint block: motor, lower limit, upper limit (wave-uniform scalar chain)
+        real dj = rdlane(du, j), di = rdlane(m_di, j), wjj = rdlane(m_wjj, j);
+        real lam = rdlane(m_lam, j), lim = rdlane(m_lim, j);
+        real dl = rdlane(m_rhs, j) - dj * di, sum = lam + dl;
+        sum = sum < -lim ? -lim : (sum > lim ? lim : sum); dl = sum - lam;
+        real r0 = dl * wjj; res2 = r0 * r0 > res2 ? r0 * r0 : res2;
+        dj += dl * wjj;
+        real ll = rdlane(lo_lam, j), d2 = rdlane(lo_rhs, j) - dj * di, s2 = ll + d2;
+        s2 = s2 < 0 ? (real)0 : s2; d2 = s2 - ll;
+        real r1 = d2 * wjj; res2 = r1 * r1 > res2 ? r1 * r1 : res2;
+        dj += d2 * wjj;
+        real lh = rdlane(hi_lam, j), d3 = rdlane(hi_rhs, j) + dj * di, s3 = lh + d3;
+        s3 = s3 < 0 ? (real)0 : s3; d3 = s3 - lh;
+        real r2 = d3 * wjj; res2 = r2 * r2 > res2 ? r2 * r2 : res2;
+        tot_a = dl + d2 - d3;
+        if (d == j) { m_lam = sum; lo_lam = s2; hi_lam = s3; }
+      }
+      // pipe joint motor j (lane 9 + j holds its state; its DOF is 15 + j)
+      real dj = rdlane(du, 15 + j), di = rdlane(m_di, 9 + j), lam = rdlane(m_lam, 9 + j), lim = rdlane(m_lim, 9 + j);
+      real dl = rdlane(m_rhs, 9 + j) - dj * di, sum = lam + dl;
+      sum = sum < -lim ? -lim : (sum > lim ? lim : sum); dl = sum - lam;
+      real rs = dl * rdlane(m_wjj, 9 + j); res2 = rs * rs > res2 ? rs * rs : res2;
+      if (d == 9 + j) m_lam = sum;
+      du += wreg[j] * (armlane ? tot_a : dl);
     }
     for (int c = 0; c < nc; c++) {
-      int la = sh.c_la[c], lb = sh.c_lb[c];
-      if (la < 0) continue;
-      V3 p = ld3(sh.c_p[c]);
-      real mu = sh.c_mu[c];
-      real lamn = sh.r_lam[3 * c];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        int row = 3 * c + k;
-        real lo = 0, hi = PIH_BIG;
-        if (k > 0) { if (!(lamn > 0)) continue; hi = mu * lamn; lo = -hi; }
-        V3 dir = ld3(sh.r_dir[row]);
-        real jd = wave_allsum(jac_entry(g, la, lb, p, dir) * du);
-        real di = sh.r_dinv[row], lam = sh.r_lam[row];
-        real dl = sh.r_rhs[row] - jd * di, sum = lam + dl;
-        if (sum < lo) { dl = lo - lam; sum = lo; } else if (sum > hi) { dl = hi - lam; sum = hi; }
-        if (d == 0) sh.r_lam[row] = sum;
-        if (k == 0) lamn = sum;
-        du += Wrow(row, c, k) * dl;
-        real rs = dl / di; res2 = rs * rs > res2 ? rs * rs : res2;
+      const real* R = sh.crec[c];
+      const int la = (int)R[3], lb = (int)R[4], ar = (int)R[6];
+      real w0 = 0, w1 = 0, w2 = 0;
+      if (pipelane) { w0 = sh.Wp[3 * c][d - 9]; w1 = sh.Wp[3 * c + 1][d - 9]; w2 = sh.Wp[3 * c + 2][d - 9]; }
+      else if (armlane && ar >= 0) { w0 = sh.Wa[3 * ar][d]; w1 = sh.Wa[3 * ar + 1][d]; w2 = sh.Wa[3 * ar + 2][d]; }
+      const V3 p = mk(R[0], R[1], R[2]);
+      const real mu = R[5];
+      // Jacobian entries of this lane's DOF for the three directions share a x (p - o)
+      real sgn = (is_anc(g.L, la) ? (real)1 : (real)0) - (is_anc(g.L, lb) ? (real)1 : (real)0);
+      V3 cv = g.kind == 0 ? cross(g.a, p - g.o) : g.a;
+      real sdu = (g.kind == 2 ? (real)0 : sgn) * du;
+      real x0 = sdu * dot(mk(R[8], R[9], R[10]), cv), x1 = sdu * dot(mk(R[12], R[13], R[14]), cv), x2 = sdu * dot(mk(R[16], R[17], R[18]), cv);
+      row16_sum3(x0, x1, x2);
+      real jd0 = rdlane(x0, 0) + rdlane(x0, 16) + rdlane(x0, 32);
+      real jd1 = rdlane(x1, 0) + rdlane(x1, 16) + rdlane(x1, 32);
+      real jd2 = rdlane(x2, 0) + rdlane(x2, 16) + rdlane(x2, 32);
+      real l0 = rdlane(cl0, c), l1 = rdlane(cl1, c), l2 = rdlane(cl2, c);
+      real di0 = R[11], di1 = R[15], di2 = R[19];
+      real dl0 = R[20] - jd0 * di0, s0 = l0 + dl0;
+      s0 = s0 < 0 ? (real)0 : s0; dl0 = s0 - l0;
+      real rs0 = dl0 / di0; res2 = rs0 * rs0 > res2 ? rs0 * rs0 : res2;
+      real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
+      if (s0 > 0) {
+        real hi = mu * s0;
+        jd1 += R[23] * dl0;
+        dl1 = R[21] - jd1 * di1; s1 = l1 + dl1; s1 = s1 < -hi ? -hi : (s1 > hi ? hi : s1); dl1 = s1 - l1;
+        real rs1 = dl1 / di1; res2 = rs1 * rs1 > res2 ? rs1 * rs1 : res2;
+        jd2 += R[24] * dl0 + R[25] * dl1;
+        dl2 = R[22] - jd2 * di2; s2 = l2 + dl2; s2 = s2 < -hi ? -hi : (s2 > hi ? hi : s2); dl2 = s2 - l2;
+        real rs2 = dl2 / di2; res2 = rs2 * rs2 > res2 ? rs2 * rs2 : res2;
       }
-      w.sync();
+      if (d == c) { cl0 = s0; cl1 = s1; cl2 = s2; }
+      du += w0 * dl0 + w1 * dl1 + w2 * dl2;
     }
     if (res2 <= P.resid) { it++; break; }
   }
-  if (d < NMOT) sh.m_lam[d] = mlam;
-  if (d < NLIM) sh.l_lam[d] = llam;
+  if (d < NMOT) sh.m_lam[d] = m_lam;
+  if (d < 9) { sh.l_lam[2 * d] = lo_lam; sh.l_lam[2 * d + 1] = hi_lam; }
+  if (d < nc) { sh.r_lam[3 * d] = cl0; sh.r_lam[3 * d + 1] = cl1; sh.r_lam[3 * d + 2] = cl2; }
   if (d < ND) sh.u[d] += du;
   w.sync();
   return it;
@@ -945,15 +1018,28 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P) {
 }
 
 // ------------------------------------------------------------------------------------------------ full step
+#ifdef PIH_HOST_EMUL
+#define PIH_STAMP(k) do { } while (0)
+#else
+// diagnostic phase stamps: shader-clock deltas go to dbg[900+k] only when config.debug == 2 (never read by the kernel)
+#define PIH_STAMP(k) do { if (dbg && P.debug == 2) { long long _t = __builtin_readcyclecounter(); if (w.lane() == 0) dbg[900 + (k)] = (real)(_t - _t0); _t0 = _t; } } while (0)
+#endif
+
 template <class W>
 PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* action, real* obs, real* reward, unsigned char* done, real* dbg) {
   real* S = sh.S;
   const real dt = P.dt;
+#ifndef PIH_HOST_EMUL
+  long long _t0 = __builtin_readcyclecounter();
+#endif
   bool frozen = !P.autoreset && S[PIH_S_DONE] != 0;   // finished envs keep their last values (envs/base_env.py:62,66)
   fk_all(w, sh);
+  PIH_STAMP(0);
   if (!frozen) {
     controller(w, sh, P, action);
+    PIH_STAMP(1);
     collide(w, sh, P);
+    PIH_STAMP(2);
     w.par(ND, [&](int d) {
       real v;
       if (d < 9) v = S[PIH_S_QDARM + d]; else if (d < 12) v = S[PIH_S_VLIN + d - 9]; else if (d < 15) v = S[PIH_S_VANG + d - 12]; else v = S[PIH_S_QDJ + d - 15];
@@ -961,6 +1047,7 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* act
     });
     aba(w, sh);
     w.par(ND, [&](int d) { sh.u[d] += dt * sh.udot[d]; });
+    PIH_STAMP(3);
     if (dbg && P.debug) {
       w.par(ND, [&](int d) { dbg[d] = sh.udot[d]; });
       w.par(sh.nc, [&](int c) {
@@ -970,7 +1057,9 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* act
       });
     }
     build_rows(w, sh, P);
+    PIH_STAMP(4);
     int iters = pgs(w, sh, P);
+    PIH_STAMP(5);
     // integrate + bookkeeping
     w.par(ND, [&](int d) {
       real v = sh.u[d];
@@ -1008,7 +1097,9 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* act
     S[PIH_S_STEPS] += 1;
     if (dbg && P.debug) { dbg[38] = (real)sh.nc; dbg[39] = (real)iters; }
     w.sync();
+    PIH_STAMP(6);
     fk_all(w, sh);
+    PIH_STAMP(7);
   }
   // outputs: declared 5-vector obs (envs/peg_in_hole.py:13), reward (:114-117), done
   V3 eep; M3 eeR; ee_pose(sh, eep, eeR);
@@ -1024,6 +1115,8 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* act
   *reward = rew; *done = (unsigned char)((S[PIH_S_DONE] != 0 || bad) ? 1 : 0);
   w.sync();
   if (bad || (P.autoreset && S[PIH_S_DONE] != 0)) {
+    if (bad) { S[PIH_S_RNG] = (S[PIH_S_RNG] == S[PIH_S_RNG] && S[PIH_S_RNG] >= 0 && S[PIH_S_RNG] < (real)1e7) ? S[PIH_S_RNG] : (real)0;
+               real nb = S[PIH_S_SPARE]; S[PIH_S_SPARE] = (nb == nb && nb >= 0 ? nb : (real)0) + 1; }   // count non-finite resets
     reset_state(S, P, P.env0 + env);
     w.sync();
     fk_all(w, sh);
