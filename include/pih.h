@@ -42,6 +42,7 @@ enum {
   PIH_S_CFORCE = 105,      /* sum of contact normal impulses / dt of the last step [N] */
   PIH_S_NCONTACT = 106,
   PIH_S_PGS_ITERS = 107,   /* PGS iterations actually executed in the last step */
+  PIH_S_EE = 108,          /* world position of the grasp-target frame (pybullet link 11) after the last step / reset (3) */
   PIH_S_CACHE_N = 128, PIH_S_CACHE_KEY = 129, PIH_S_CACHE_LAMBDA = 129 + 48
 };
 
@@ -50,7 +51,8 @@ enum {
   PIH_FIELD_STATE = 0,         /* float[n, PIH_STATE_WORDS] */
   PIH_FIELD_TIP_POSE = 1,      /* float[n, 7]  (get only)  envs/peg_in_hole.py:58,115 */
   PIH_FIELD_CONTACT_FORCE = 2, /* float[n]     (get only)  north_star contact-normal force */
-  PIH_FIELD_DEBUG = 3          /* float[n, PIH_DEBUG_WORDS] (get only; filled when config.debug != 0) */
+  PIH_FIELD_DEBUG = 3,         /* float[n, PIH_DEBUG_WORDS] (get only; filled when config.debug != 0) */
+  PIH_FIELD_EE_POS = 4         /* float[n, 3]  (get only)  envs/utils.py:62 getLinkState(panda, 11)[0] */
 };
 
 typedef struct pih_config {

@@ -444,7 +444,7 @@ static void reset_env(piho_handle* h, int e) {
   double* s = E->s;
   double off[3] = {s[PIHO_S_OFFSET], s[PIHO_S_OFFSET + 1], s[PIHO_S_OFFSET + 2]}, nbad = s[PIHO_S_SPARE];
   uint64_t ctr = (uint64_t)s[PIHO_S_RNG];
-  uint64_t seed = h->cfg.seed + 1000ULL + (uint64_t)e;
+  uint64_t seed = h->cfg.seed + 1000ULL + (uint64_t)(h->cfg.env_index0 + e);
   memset(s, 0, sizeof(double) * PIHO_STATE_WORDS);
   for (int k = 0; k < 3; k++) s[PIHO_S_OFFSET + k] = off[k];
   s[PIHO_S_SPARE] = nbad;

@@ -10,7 +10,7 @@ STATE_WORDS = 256
 DEBUG_WORDS = 1024
 ACTION_DIM = 4
 OBS_DIM = 5
-FIELD_STATE, FIELD_TIP_POSE, FIELD_CONTACT_FORCE, FIELD_DEBUG = 0, 1, 2, 3
+FIELD_STATE, FIELD_TIP_POSE, FIELD_CONTACT_FORCE, FIELD_DEBUG, FIELD_EE_POS = 0, 1, 2, 3, 4
 # state record word offsets (include/pih.h)
 S_QARM, S_QDARM, S_POS, S_QUAT, S_VLIN, S_VANG, S_QJ, S_QDJ, S_TARGET = 0, 9, 18, 21, 25, 28, 31, 54, 77
 S_FSM, S_FSMT, S_DONE, S_GRASP, S_RANDY, S_ATTACH, S_RNG, S_STEPS, S_OFFSET = 86, 87, 88, 89, 90, 91, 92, 93, 94

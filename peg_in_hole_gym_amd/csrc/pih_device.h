@@ -1107,6 +1107,7 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* act
   V3 dh = mk(tip[0], tip[1], tip[2]) - ld3(HOLE_POS);
   real rew = norm(dh) < (real)0.05 ? (real)1 : (real)0;
   for (int i = 0; i < 7; i++) S[PIH_S_TIP + i] = tip[i];
+  S[PIH_S_EE] = eep.x + S[PIH_S_OFFSET]; S[PIH_S_EE + 1] = eep.y + S[PIH_S_OFFSET + 1]; S[PIH_S_EE + 2] = eep.z + S[PIH_S_OFFSET + 2];
   bool bad = false;
   for (int i = 0; i < 86; i++) { real v = S[i]; bad = bad || !(v == v) || absr(v) > (real)1e15; }
   if (!frozen && P.mode == 0 && (rew > 0 || S[PIH_S_STEPS] >= (real)P.maxsteps)) S[PIH_S_DONE] = 1;
@@ -1122,6 +1123,8 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* act
     fk_all(w, sh);
     real tp2[7]; tip_pose(sh, tp2);
     for (int i = 0; i < 7; i++) S[PIH_S_TIP + i] = tp2[i];
+    V3 e2; M3 r2; ee_pose(sh, e2, r2);
+    S[PIH_S_EE] = e2.x + S[PIH_S_OFFSET]; S[PIH_S_EE + 1] = e2.y + S[PIH_S_OFFSET + 1]; S[PIH_S_EE + 2] = e2.z + S[PIH_S_OFFSET + 2];
     w.sync();
   }
 }

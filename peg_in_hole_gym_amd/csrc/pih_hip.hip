@@ -47,6 +47,8 @@ __global__ void __launch_bounds__(64) pih_reset_kernel(Params P, float* __restri
   fk_all(w, sh);
   float tip[7]; tip_pose(sh, tip);
   for (int i = 0; i < 7; i++) sh.S[PIH_S_TIP + i] = tip[i];
+  V3 ee; M3 eR; ee_pose(sh, ee, eR);
+  sh.S[PIH_S_EE] = ee.x + sh.S[PIH_S_OFFSET]; sh.S[PIH_S_EE + 1] = ee.y + sh.S[PIH_S_OFFSET + 1]; sh.S[PIH_S_EE + 2] = ee.z + sh.S[PIH_S_OFFSET + 2];
   __syncthreads();
   for (int i = 0; i < PIH_STATE_WORDS / 64; i++) rec[lane + 64 * i] = sh.S[lane + 64 * i];
 }
@@ -206,6 +208,7 @@ int pih_get_state(pih_handle* h, int field, void* out_dev, void* stream) {
     case PIH_FIELD_STATE: HIPCHK(h, hipMemcpyAsync(out_dev, h->state, (size_t)n * PIH_STATE_WORDS * sizeof(float), hipMemcpyDeviceToDevice, s)); return 0;
     case PIH_FIELD_TIP_POSE: hipLaunchKernelGGL(pih_gather_kernel, dim3((n * 7 + 255) / 256), dim3(256), 0, s, h->state, (float*)out_dev, n, (int)PIH_S_TIP, 7); break;
     case PIH_FIELD_CONTACT_FORCE: hipLaunchKernelGGL(pih_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->state, (float*)out_dev, n, (int)PIH_S_CFORCE, 1); break;
+    case PIH_FIELD_EE_POS: hipLaunchKernelGGL(pih_gather_kernel, dim3((n * 3 + 255) / 256), dim3(256), 0, s, h->state, (float*)out_dev, n, (int)PIH_S_EE, 3); break;
     case PIH_FIELD_DEBUG:
       if (!h->dbg) { h->err = "pih_get_state: debug buffer not enabled (config.debug = 0)"; return -4; }
       HIPCHK(h, hipMemcpyAsync(out_dev, h->dbg, (size_t)n * PIH_DEBUG_WORDS * sizeof(float), hipMemcpyDeviceToDevice, s)); return 0;

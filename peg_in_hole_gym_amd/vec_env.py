@@ -94,6 +94,10 @@ class PihVecEnv:
         with torch.cuda.device(self.device):
             self._chk(self.L.pih_set_state(self.h, _lib.FIELD_STATE, s.data_ptr(), self._stream()), "pih_set_state")
 
+    def ee_position(self):
+        """World position of the grasp-target frame (pybullet link 11) after the last step / reset."""
+        return self._get(_lib.FIELD_EE_POS, (self.n, 3))
+
     def tip_pose(self):
         return self._get(_lib.FIELD_TIP_POSE, (self.n, 7))
 
