@@ -760,7 +760,9 @@ static void step_env(piho_handle* h, int e, const double* action, double* obs, d
     if (res2 <= c->residual_threshold) break;
   }
   for (int i = 0; i < ND; i++) u[i] += dv[i];
-  for (int i = 0; i < ND; i++) if (i < 9 || i >= 15) u[i] = clampd(u[i], -MAX_COORD_VEL, MAX_COORD_VEL);
+  /* btMultiBody m_maxCoordinateVelocity = 100 on EVERY coordinate velocity, floating base included [UNVERIFIED App. C];
+   * it also keeps the explicit gyroscopic term stable (|w| dt <= 0.42) when a finger slaps the 11-gram tip link */
+  for (int i = 0; i < ND; i++) u[i] = clampd(u[i], -MAX_COORD_VEL, MAX_COORD_VEL);
 
   /* warm-start cache + contact normal force (p11) */
   E->ncache = nc; E->contact_force = 0;

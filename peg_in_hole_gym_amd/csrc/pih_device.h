@@ -31,7 +31,9 @@ constexpr int NL = PIH_NL, ANL = PIH_ARM_NL, ONL = PIH_OBJ_NL, ND = PIH_NDOF;
 constexpr int NSAMP = PIH_PIPE_NSAMP;
 constexpr int CMAX = 48;      // contacts per env
 constexpr int CAMAX = 12;     // of which may involve the arm
+constexpr int CL = 16;        // contacts whose solver data live in LDS; contacts CL..CMAX-1 spill to a global scratch
 constexpr int NROWC = 3 * CMAX;
+constexpr int CREC = 32;      // words per packed contact record
 constexpr int WPS = 31;       // LDS row stride of the pipe response rows (29 used, odd => conflict free)
 constexpr int NMOT = 32;      // 9 arm + 23 pipe joint motors
 constexpr int NLIM = 18;
@@ -85,34 +87,59 @@ struct Params {
 // dof index of link L: arm link i -> i ; pipe root (link 9) -> 9..14 (lin xyz, ang xyz) ; pipe link L>=10 -> L+5
 PIH_HD int link_dof(int L) { return L < ANL ? L : (L == ANL ? 9 : L + 5); }
 
+// Packed per-contact solver record (CREC = 32 words, 128-bit aligned so the PGS loop reads it with b128 broadcasts):
+//  0-2 p | 3 linkA | 4 linkB | 5 mu | 6 arm-row slot | 7 -
+//  8-10 n | 11 dinv_n | 12-14 t1 | 15 dinv_t1 | 16-18 t2 | 19 dinv_t2
+//  20-22 rhs (n,t1,t2) | 23 G[t1][n] | 24 G[t2][n] | 25 G[t2][t1] | 26-28 dvp_n | 29-31 dvp_t1
+// (dvp_k = relative velocity change at the contact point per unit impulse along direction k; G[a][b] = dir_a . dvp_b
+//  are the cross terms that make the in-block (n, t1, t2) update exact Gauss-Seidel)
+
+// LDS is time-multiplexed: the kinematics / ABA scratch (arena A) is dead once the free velocity update is done, the
+// solver scratch (arena B) is dead once the PGS result has been folded into the velocities.
+struct ArenaA {
+  real Tl[NL][12];                 // local (parent->link) transforms
+  real LR[NL][9], LRC[NL][3], LIC[NL][6];   // world rotation, com offset, inertia about com (world axes)
+  areal IA[NL][21], PA[NL][6];     // articulated inertia (A6 B9 C6) / bias force accumulators
+  real CB[NL][6];                  // velocity-product accelerations, then (alpha, acc) of each link
+  real SP[NSAMP][3];               // collision sample spheres
+};
+struct ArenaB {
+  // response rows of the first CL contacts; the 32 motor response rows (Wmp 23 x WPS, then Wma 9 x 9) are staged in the
+  // same words first and pulled into registers before the contact rows overwrite them
+  real Wp[3 * CL][WPS];
+  real Wa[3 * CAMAX][9];
+  real crec[CL][CREC];
+};
+constexpr int WMA_OFF = PIH_OBJ_NJ * WPS;   // word offset of Wma inside ArenaB::Wp
+static_assert(WMA_OFF + 81 <= 3 * CL * WPS, "motor response rows must fit in the Wp region");
+
 struct Shared {
   real S[PIH_STATE_WORDS];
-  real Tl[NL][12];                 // local (parent->link) transforms
-  real LR[NL][9], LO[NL][3], LA[NL][3], LRC[NL][3], LIC[NL][6];   // world pose, joint axis, com offset, inertia
+  real LO[NL][3], LA[NL][3];       // world link origins and joint axes
   real VW[NL][3], VV[NL][3];       // link angular velocity, velocity of the link-origin point
-  areal IA[NL][21], PA[NL][6];     // articulated inertia (A6 B9 C6) / bias force accumulators
-  real CB[NL][6];                  // velocity-product accelerations
   real AU[NL][6], ADinv[NL], Au[NL], AR[NL][3];   // U = I^A S, 1/D, u, r = o_L - o_parent
   real Inv6[36];
   real u[ND], udot[ND];
-  real SP[NSAMP][3];
   int c_la[CMAX], c_lb[CMAX], c_key[CMAX], c_arow[CMAX];
   real c_p[CMAX][3], c_n[CMAX][3], c_depth[CMAX], c_mu[CMAX];
   int nc, nca;
-  real r_dir[NROWC][3], r_dinv[NROWC], r_rhs[NROWC], r_lam[NROWC], r_dvp[NROWC][3];
-  real crec[CMAX][32];            // packed per-contact solver record (see pack_contacts)
-  real Wp[NROWC][WPS];
-  real Wa[3 * CAMAX][9];
+  real r_lam[NROWC];
   real m_vt[NMOT], m_maximp[NMOT], m_dinv[NMOT], m_rhs[NMOT], m_lam[NMOT];
-  real Wmp[PIH_OBJ_NJ][WPS];
-  real Wma[9][9];
   real l_rhs[NLIM], l_lam[NLIM];
   real ik_T[7][12];
-  real scratch[8];
+  union { ArenaA a; ArenaB b; };
 #ifdef PIH_HOST_EMUL
   real du[ND];
+  real hWmp[PIH_OBJ_NJ][WPS], hWma[9][9];   // host emulation keeps the motor rows in memory (the GPU keeps them in registers)
 #endif
 };
+// global spill area of one env: response rows and records of contacts CL..CMAX-1
+constexpr int OVF_W_WORDS = 3 * (CMAX - CL) * WPS, OVF_REC_WORDS = (CMAX - CL) * CREC, OVF_WORDS = OVF_W_WORDS + OVF_REC_WORDS;
+struct Ovf { real* base; };
+PIH_HD real* wp_row(Shared& sh, const Ovf& ov, int row) { return row < 3 * CL ? sh.b.Wp[row] : ov.base + (size_t)(row - 3 * CL) * WPS; }
+PIH_HD real* crec_of(Shared& sh, const Ovf& ov, int c) { return c < CL ? sh.b.crec[c] : ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC; }
+PIH_HD real* wmp_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + j * WPS; }
+PIH_HD real* wma_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + WMA_OFF + j * 9; }
 
 // ------------------------------------------------------------------------------------------------ wave context
 #ifdef PIH_HOST_EMUL
@@ -172,34 +199,34 @@ PIH_HD void local_transform(int L, real q, const real* S, real* T) {
 template <class W> PIH_HD void fk_all(W& w, Shared& sh) {
   w.par(NL, [&](int L) {
     real q = L < ANL ? sh.S[PIH_S_QARM + L] : (L == ANL ? (real)0 : sh.S[PIH_S_QJ + L - ANL - 1]);
-    local_transform(L, q, sh.S, sh.Tl[L]);
+    local_transform(L, q, sh.S, sh.a.Tl[L]);
   });
   // serial composition down the two chains (wave-uniform)
   for (int L = 0; L < NL; L++) {
     int p = L_PARENT[L];
-    M3 Tl = ldm(sh.Tl[L]); V3 tl = ld3(sh.Tl[L] + 9);
+    M3 Tl = ldm(sh.a.Tl[L]); V3 tl = ld3(sh.a.Tl[L] + 9);
     M3 R; V3 o;
     if (L_JTYPE[L] == PIH_JT_FLOATING) { R = Tl; o = tl; }
     else if (p < 0) { M3 Rp = ldm(ARM_BASE_R); R = mul(Rp, Tl); o = mul(Rp, tl); }
-    else { M3 Rp = ldm(sh.LR[p]); R = mul(Rp, Tl); o = ld3(sh.LO[p]) + mul(Rp, tl); }
-    stm(sh.LR[L], R); st3(sh.LO[L], o);
+    else { M3 Rp = ldm(sh.a.LR[p]); R = mul(Rp, Tl); o = ld3(sh.LO[p]) + mul(Rp, tl); }
+    stm(sh.a.LR[L], R); st3(sh.LO[L], o);
   }
   w.par(NL, [&](int L) {
-    M3 R = ldm(sh.LR[L]);
+    M3 R = ldm(sh.a.LR[L]);
     st3(sh.LA[L], mul(R, ld3(L_AXIS[L])));
-    st3(sh.LRC[L], mul(R, ld3(L_COM[L])));
-    sts3(sh.LIC[L], rot_sym(R, lds3(L_INERTIA[L])));
+    st3(sh.a.LRC[L], mul(R, ld3(L_COM[L])));
+    sts3(sh.a.LIC[L], rot_sym(R, lds3(L_INERTIA[L])));
   });
 }
 PIH_HD void ee_pose(const Shared& sh, V3& p, M3& R) {
-  M3 Rp = ldm(sh.LR[PIH_EE_PARENT]);
+  M3 Rp = ldm(sh.a.LR[PIH_EE_PARENT]);
   R = mul(Rp, ldm(EE_R)); p = ld3(sh.LO[PIH_EE_PARENT]) + mul(Rp, ld3(EE_T));
 }
 // getLinkState(pipe, grasp_joint_idx)[0:2]: COM frame of pipe_link1 (idx 0) / pipe_link24 (idx 23)
 PIH_HD void tip_pose(const Shared& sh, real* out) {
   int g = (int)sh.S[PIH_S_GRASP];
   int L = g == 0 ? ANL : NL - 1;
-  M3 R = ldm(sh.LR[L]);
+  M3 R = ldm(sh.a.LR[L]);
   V3 p = ld3(sh.LO[L]) + mul(R, mk(0, g == 0 ? (real)0.045 : (real)0.015, 0));
   Q4 q = m_to_q(R);
   out[0] = p.x; out[1] = p.y; out[2] = p.z; out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
@@ -387,8 +414,8 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
   const real r = (real)PIH_PIPE_RADIUS, margin = P.margin;
   w.par(NSAMP, [&](int i) {
     int L = ANL + SAMP_LINK[i];
-    V3 p = ld3(sh.LO[L]) + mul(ldm(sh.LR[L]), mk(0, SAMP_Y[i], 0));
-    st3(sh.SP[i], p);
+    V3 p = ld3(sh.LO[L]) + mul(ldm(sh.a.LR[L]), mk(0, SAMP_Y[i], 0));
+    st3(sh.a.SP[i], p);
   });
   auto emit = [&](int slot, int la, int lb, int key, V3 p, V3 n, real depth, real mu) {
     sh.c_la[slot] = la; sh.c_lb[slot] = lb; sh.c_key[slot] = key; st3(sh.c_p[slot], p); st3(sh.c_n[slot], n);
@@ -399,7 +426,7 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
   w.par_all(NSAMP, [&](int i, bool in) {
     bool valid = false; V3 sp = mk(0, 0, 0); real depth = 0; int L = 0;
     if (in && SAMP_VERTEX[i]) {
-      sp = ld3(sh.SP[i]); depth = sp.z - (real)PIH_TABLE_Z - r; L = ANL + SAMP_LINK[i];
+      sp = ld3(sh.a.SP[i]); depth = sp.z - (real)PIH_TABLE_Z - r; L = ANL + SAMP_LINK[i];
       valid = depth < margin;
     }
     int slot = w.alloc(valid);
@@ -414,7 +441,7 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
   w.par_all(NSAMP, [&](int i, bool in) {
     bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = 0; int L = 0;
     if (in) {
-      V3 sp = ld3(sh.SP[i]); V3 d = sp - ld3(HOLE_POS);
+      V3 sp = ld3(sh.a.SP[i]); V3 d = sp - ld3(HOLE_POS);
       real a = d.x, rho = (real)sqrt(d.y * d.y + d.z * d.z);
       real dx = absr(a) - hl, dy = absr(rho - rcx) - hw;
       if (!(dx > r + margin || dy > r + margin)) {
@@ -435,13 +462,13 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
   int nca = 0;
   for (int f = 0; f < 2; f++) {
     const int LF = PIH_FINGER_LINK0 + f;
-    M3 Rf = ldm(sh.LR[LF]); V3 bc = ld3(sh.LO[LF]) + mul(Rf, ld3(FBOX_C[f])); V3 bh = ld3(FBOX_H);
+    M3 Rf = ldm(sh.a.LR[LF]); V3 bc = ld3(sh.LO[LF]) + mul(Rf, ld3(FBOX_C[f])); V3 bh = ld3(FBOX_H);
     const int before = w.alloc_count();
     const int allowed = CAMAX - nca;   // arm-involving contacts are capped (their arm response rows live in Wa)
     w.par_all(NSAMP, [&](int i, bool in) {
       bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = 0; int L = 0;
       if (in) {
-        V3 sp = ld3(sh.SP[i]); V3 d = sp - bc;
+        V3 sp = ld3(sh.a.SP[i]); V3 d = sp - bc;
         if (dot(d, d) <= (real)(0.05 * 0.05)) {
           V3 pl = tmul(Rf, d);
           V3 q = mk(clampr(pl.x, -bh.x, bh.x), clampr(pl.y, -bh.y, bh.y), clampr(pl.z, -bh.z, bh.z));
@@ -476,7 +503,7 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
         while (rem >= 22 - s) { rem -= 22 - s; s++; }
         t = s + 2 + rem;
         // vertex v = first sample of segment v (v<24) / last sample (v=24): sample index of vertex v
-        auto vtx = [&](int v) -> V3 { int si = v == 0 ? 0 : (v == 24 ? NSAMP - 1 : 7 + 5 * (v - 1)); return ld3(sh.SP[si]); };
+        auto vtx = [&](int v) -> V3 { int si = v == 0 ? 0 : (v == 24 ? NSAMP - 1 : 7 + 5 * (v - 1)); return ld3(sh.a.SP[si]); };
         V3 p1 = vtx(s), q1 = vtx(s + 1), p2 = vtx(t), q2 = vtx(t + 1);
         V3 dm = (p1 + q1) - (p2 + q2);
         if (dot(dm, dm) <= (real)(4 * 0.12 * 0.12)) {
@@ -533,10 +560,10 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
   w.par(NL, [&](int L) {
     int p = L_PARENT[L], jt = L_JTYPE[L];
     real m = L_MASS[L];
-    V3 rc = ld3(sh.LRC[L]); S3 Ic = lds3(sh.LIC[L]);
+    V3 rc = ld3(sh.a.LRC[L]); S3 Ic = lds3(sh.a.LIC[L]);
     V3 wv = ld3(sh.VW[L]), vv = ld3(sh.VV[L]);
     // A = Ic + m (|rc|^2 1 - rc rc^T), B = m [rc]x, C = m 1
-    areal* I = sh.IA[L];
+    areal* I = sh.a.IA[L];
     real r2 = dot(rc, rc);
     I[0] = Ic.xx + m * (r2 - rc.x * rc.x); I[1] = Ic.yy + m * (r2 - rc.y * rc.y); I[2] = Ic.zz + m * (r2 - rc.z * rc.z);
     I[3] = Ic.xy - m * rc.x * rc.y; I[4] = Ic.xz - m * rc.x * rc.z; I[5] = Ic.yz - m * rc.y * rc.z;
@@ -550,7 +577,7 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
       cl = cross(wp, cross(wp, r));
       if (jt == PIH_JT_REVOLUTE) ca = cross(wp, aq); else cl = cl + (real)2 * cross(wp, aq);
     }
-    st3(sh.CB[L], ca); st3(sh.CB[L] + 3, cl); st3(sh.AR[L], r);
+    st3(sh.a.CB[L], ca); st3(sh.a.CB[L] + 3, cl); st3(sh.AR[L], r);
     // bias force: velocity products minus gravity minus Bullet link damping
     V3 wrc = cross(wv, rc);
     V3 vc = vv + wrc;
@@ -558,16 +585,16 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
     real sv = PIH_LIN_DAMP + PIH_LIN_DAMP * norm(vc), sw = PIH_ANG_DAMP + PIH_ANG_DAMP * norm(wv);
     V3 f = m * cross(wv, wrc) - mk(0, 0, m * (real)PIH_GRAVITY_Z) + (m * sv) * vc;
     V3 n = cross(wv, Iw) + sw * Iw + cross(rc, f);
-    sh.PA[L][0] = n.x; sh.PA[L][1] = n.y; sh.PA[L][2] = n.z; sh.PA[L][3] = f.x; sh.PA[L][4] = f.y; sh.PA[L][5] = f.z;
+    sh.a.PA[L][0] = n.x; sh.a.PA[L][1] = n.y; sh.a.PA[L][2] = n.z; sh.a.PA[L][3] = f.x; sh.a.PA[L][4] = f.y; sh.a.PA[L][5] = f.z;
   });
   // inward sweep (wave-uniform)
   for (int L = NL - 1; L >= 0; L--) {
     int p = L_PARENT[L], jt = L_JTYPE[L];
-    const areal* I = sh.IA[L];
+    const areal* I = sh.a.IA[L];
     areal A[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]};
     areal B[9]; for (int i = 0; i < 9; i++) B[i] = I[6 + i];
     areal C[9] = {I[15], I[18], I[19], I[18], I[16], I[20], I[19], I[20], I[17]};
-    areal pa[3] = {sh.PA[L][0], sh.PA[L][1], sh.PA[L][2]}, pl[3] = {sh.PA[L][3], sh.PA[L][4], sh.PA[L][5]};
+    areal pa[3] = {sh.a.PA[L][0], sh.a.PA[L][1], sh.a.PA[L][2]}, pl[3] = {sh.a.PA[L][3], sh.a.PA[L][4], sh.a.PA[L][5]};
     if (jt == PIH_JT_FLOATING) {
       // root: invert the 6x6 articulated inertia [[A,B],[B^T,C]] (order: angular, linear) by Gauss-Jordan (SPD)
       areal Mx[6][6], Iv[6][6];
@@ -605,7 +632,7 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
     // I^a = I^A - U U^T / D
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { A[3 * i + j] -= Ua[i] * Ua[j] * Di; B[3 * i + j] -= Ua[i] * Ul[j] * Di; C[3 * i + j] -= Ul[i] * Ul[j] * Di; }
     // p^a = p^A + I^a c + U u / D
-    const areal ca[3] = {sh.CB[L][0], sh.CB[L][1], sh.CB[L][2]}, cl[3] = {sh.CB[L][3], sh.CB[L][4], sh.CB[L][5]};
+    const areal ca[3] = {sh.a.CB[L][0], sh.a.CB[L][1], sh.a.CB[L][2]}, cl[3] = {sh.a.CB[L][3], sh.a.CB[L][4], sh.a.CB[L][5]};
     areal ud = u * Di, qa[3], ql[3];
     for (int i = 0; i < 3; i++) {
       qa[i] = pa[i] + A[3 * i] * ca[0] + A[3 * i + 1] * ca[1] + A[3 * i + 2] * ca[2] + B[3 * i] * cl[0] + B[3 * i + 1] * cl[1] + B[3 * i + 2] * cl[2] + ud * Ua[i];
@@ -624,14 +651,14 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
       areal mx = Bn[3 * i], my = Bn[3 * i + 1], mz = Bn[3 * i + 2];
       Y[3 * i] = my * r[2] - mz * r[1]; Y[3 * i + 1] = mz * r[0] - mx * r[2]; Y[3 * i + 2] = mx * r[1] - my * r[0];
     }
-    areal* Ip = sh.IA[p];
+    areal* Ip = sh.a.IA[p];
     Ip[0] += A[0] + X[0] - Y[0]; Ip[1] += A[4] + X[4] - Y[4]; Ip[2] += A[8] + X[8] - Y[8];
     Ip[3] += A[1] + (areal)0.5 * ((X[1] - Y[1]) + (X[3] - Y[3]));
     Ip[4] += A[2] + (areal)0.5 * ((X[2] - Y[2]) + (X[6] - Y[6]));
     Ip[5] += A[5] + (areal)0.5 * ((X[5] - Y[5]) + (X[7] - Y[7]));
     for (int i = 0; i < 9; i++) Ip[6 + i] += Bn[i];
     Ip[15] += C[0]; Ip[16] += C[4]; Ip[17] += C[8]; Ip[18] += C[1]; Ip[19] += C[2]; Ip[20] += C[5];
-    areal* Pp = sh.PA[p];
+    areal* Pp = sh.a.PA[p];
     Pp[0] += qa[0] + (r[1] * ql[2] - r[2] * ql[1]); Pp[1] += qa[1] + (r[2] * ql[0] - r[0] * ql[2]); Pp[2] += qa[2] + (r[0] * ql[1] - r[1] * ql[0]);
     Pp[3] += ql[0]; Pp[4] += ql[1]; Pp[5] += ql[2];
   }
@@ -640,17 +667,17 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
     int p = L_PARENT[L], jt = L_JTYPE[L], d = link_dof(L);
     V3 al, ac;
     if (jt == PIH_JT_FLOATING) {
-      real pv[6]; for (int i = 0; i < 6; i++) pv[i] = (real)sh.PA[L][i];
+      real pv[6]; for (int i = 0; i < 6; i++) pv[i] = (real)sh.a.PA[L][i];
       real x[6];
       for (int i = 0; i < 6; i++) { real s = 0; for (int j = 0; j < 6; j++) s -= sh.Inv6[6 * i + j] * pv[j]; x[i] = s; }
       al = mk(x[0], x[1], x[2]); ac = mk(x[3], x[4], x[5]);
       sh.udot[d] = ac.x; sh.udot[d + 1] = ac.y; sh.udot[d + 2] = ac.z; sh.udot[d + 3] = al.x; sh.udot[d + 4] = al.y; sh.udot[d + 5] = al.z;
     } else {
       V3 alp = mk(0, 0, 0), acp = mk(0, 0, 0);
-      if (p >= 0) { alp = ld3(sh.CB[p]); acp = ld3(sh.CB[p] + 3); }   // parent's (alpha, acc) stored below
+      if (p >= 0) { alp = ld3(sh.a.CB[p]); acp = ld3(sh.a.CB[p] + 3); }   // parent's (alpha, acc) stored below
       V3 r = ld3(sh.AR[L]);
-      V3 aa = alp + ld3(sh.CB[L]);
-      V3 ll = acp + cross(alp, r) + ld3(sh.CB[L] + 3);
+      V3 aa = alp + ld3(sh.a.CB[L]);
+      V3 ll = acp + cross(alp, r) + ld3(sh.a.CB[L] + 3);
       V3 Ua = ld3(sh.AU[L]), Ul = ld3(sh.AU[L] + 3);
       real qdd = (sh.Au[L] - dot(Ua, aa) - dot(Ul, ll)) * sh.ADinv[L];
       V3 a = ld3(sh.LA[L]);
@@ -658,7 +685,7 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
       sh.udot[d] = qdd;
     }
     // overwrite this link's c with its (alpha, acc): c of a link is never needed again once it has been visited
-    st3(sh.CB[L], al); st3(sh.CB[L] + 3, ac);
+    st3(sh.a.CB[L], al); st3(sh.a.CB[L] + 3, ac);
   }
 }
 
@@ -751,7 +778,11 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
 
 PIH_HD V3 point_vel(const Shared& sh, int L, V3 p) { return ld3(sh.VV[L]) + cross(ld3(sh.VW[L]), p - ld3(sh.LO[L])); }
 
-template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P) {
+// motor response rows held per lane (lane = DOF): arm lanes hold column d of the 9x9 arm block, pipe lanes column d-9 of
+// the 23 x 29 pipe block.  On the GPU these stay in registers across the contact-row pass (their LDS words are reused).
+struct MotorW { real w[PIH_OBJ_NJ]; };
+
+template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, const Ovf& ov, MotorW& mw) {
   const real dt = P.dt;
   // link velocities after the free update (contact / motor right-hand sides)
   link_velocities(sh);
@@ -763,7 +794,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P) {
   // motor rows (lane = motor): response of a unit joint impulse; limit rows share W and 1/(J W)
   w.par(NMOT, [&](int m) {
     int L = m < 9 ? m : ANL + 1 + (m - 9);
-    RowOut o; o.wa = m < 9 ? sh.Wma[m] : nullptr; o.wp = m < 9 ? nullptr : sh.Wmp[m - 9];
+    RowOut o; o.wa = m < 9 ? wma_row(sh, m) : nullptr; o.wp = m < 9 ? nullptr : wmp_row(sh, m - 9);
     real jw = response(sh, -1, -1, mk(0, 0, 0), mk(0, 0, 0), L, o);
     real di = (real)1 / jw;
     int d = link_dof(L);
@@ -777,20 +808,30 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P) {
     real sg = side == 0 ? (real)1 : (real)-1;
     sh.l_rhs[k] = (vb - sg * sh.u[L]) * sh.m_dinv[L]; sh.l_lam[k] = 0;
   });
-  // contact rows (lane = row): row 3c+k, k = 0 normal, 1/2 friction directions
+  // pull the motor rows out of the staging words before the contact rows overwrite them
+#ifdef PIH_HOST_EMUL
+  for (int j = 0; j < PIH_OBJ_NJ; j++) for (int k = 0; k < 29; k++) sh.hWmp[j][k] = wmp_row(sh, j)[k];
+  for (int j = 0; j < 9; j++) for (int k = 0; k < 9; k++) sh.hWma[j][k] = wma_row(sh, j)[k];
+  (void)mw;
+#else
+  {
+    const int d = w.lane();
+#pragma unroll
+    for (int j = 0; j < PIH_OBJ_NJ; j++) mw.w[j] = d < 9 ? (j < 9 ? wma_row(sh, j)[d] : (real)0) : (d < ND ? wmp_row(sh, j)[d - 9] : (real)0);
+  }
+#endif
+  // contact rows (lane = row): row 3c+k, k = 0 normal, 1/2 friction directions; results go straight into the packed record
   w.par(3 * sh.nc, [&](int row) {
     int c = row / 3, k = row - 3 * c;
     int la = sh.c_la[c], lb = sh.c_lb[c];
     V3 n = ld3(sh.c_n[c]), p = ld3(sh.c_p[c]);
     V3 t1, t2; plane_space(n, t1, t2);
     V3 dir = k == 0 ? n : (k == 1 ? t1 : t2);
-    st3(sh.r_dir[row], dir);
-    if (la < 0) { sh.r_dinv[row] = 0; sh.r_rhs[row] = 0; sh.r_lam[row] = 0; for (int i = 0; i < 29; i++) sh.Wp[row][i] = 0; return; }
+    real* R = crec_of(sh, ov, c);
     int ar = sh.c_arow[c];
-    RowOut o; o.wp = sh.Wp[row]; o.wa = ar >= 0 ? sh.Wa[3 * ar + k] : nullptr;
+    RowOut o; o.wp = wp_row(sh, ov, row); o.wa = ar >= 0 ? sh.b.Wa[3 * ar + k] : nullptr;
     V3 dvp;
     real jw = response(sh, la, lb, p, dir, -1, o, &dvp);
-    st3(sh.r_dvp[row], dvp);
     real di = (real)1 / jw;
     V3 vr = point_vel(sh, la, p);
     if (lb >= 0) vr = vr - point_vel(sh, lb, p);
@@ -802,22 +843,18 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P) {
       rhs = (vb - ju) * di;
       int ncache = (int)sh.S[PIH_S_CACHE_N]; real key = (real)sh.c_key[c];
       for (int i = 0; i < ncache; i++) if (sh.S[PIH_S_CACHE_KEY + i] == key) { lam = P.warm * sh.S[PIH_S_CACHE_LAMBDA + i]; break; }
+      R[0] = p.x; R[1] = p.y; R[2] = p.z; R[3] = (real)la; R[4] = (real)lb; R[5] = sh.c_mu[c]; R[6] = (real)ar; R[7] = 0;
     } else rhs = -ju * di;
-    sh.r_dinv[row] = di; sh.r_rhs[row] = rhs; sh.r_lam[row] = lam;
+    R[8 + 4 * k] = dir.x; R[9 + 4 * k] = dir.y; R[10 + 4 * k] = dir.z; R[11 + 4 * k] = di;
+    R[20 + k] = rhs;
+    if (k < 2) { R[26 + 3 * k] = dvp.x; R[27 + 3 * k] = dvp.y; R[28 + 3 * k] = dvp.z; }
+    sh.r_lam[row] = lam;
   });
-  // pack one solver record per contact (lane = contact): everything the PGS block update needs, 128-bit aligned, plus
-  // the cross terms G[a][b] = J_a W_b^T = dir_a . dvp_b that make the in-block (n, t1, t2) update exact Gauss-Seidel
+  // cross terms of each contact block (lane = contact)
   w.par(sh.nc, [&](int c) {
-    real* R = sh.crec[c];
-    R[0] = sh.c_p[c][0]; R[1] = sh.c_p[c][1]; R[2] = sh.c_p[c][2]; R[3] = (real)sh.c_la[c];
-    R[4] = (real)sh.c_lb[c]; R[5] = sh.c_mu[c]; R[6] = (real)sh.c_arow[c]; R[7] = 0;
-    for (int k = 0; k < 3; k++) { R[8 + 4 * k] = sh.r_dir[3 * c + k][0]; R[9 + 4 * k] = sh.r_dir[3 * c + k][1]; R[10 + 4 * k] = sh.r_dir[3 * c + k][2]; R[11 + 4 * k] = sh.r_dinv[3 * c + k]; }
-    R[20] = sh.r_rhs[3 * c]; R[21] = sh.r_rhs[3 * c + 1]; R[22] = sh.r_rhs[3 * c + 2];
-    V3 t1 = ld3(sh.r_dir[3 * c + 1]), t2 = ld3(sh.r_dir[3 * c + 2]);
-    R[23] = dot(t1, ld3(sh.r_dvp[3 * c]));       // G[t1][n]
-    R[24] = dot(t2, ld3(sh.r_dvp[3 * c]));       // G[t2][n]
-    R[25] = dot(t2, ld3(sh.r_dvp[3 * c + 1]));   // G[t2][t1]
-    R[26] = 0; R[27] = 0; R[28] = 0; R[29] = 0; R[30] = 0; R[31] = 0;
+    real* R = crec_of(sh, ov, c);
+    V3 t1 = ld3(R + 12), t2 = ld3(R + 16), dn = ld3(R + 26), d1 = ld3(R + 29);
+    R[23] = dot(t1, dn); R[24] = dot(t2, dn); R[25] = dot(t2, d1);
   });
 }
 
@@ -869,57 +906,61 @@ PIH_HD void row16_sum3(real& a, real& b, real& c) {
 // registers (v_readlane to broadcast); motor response rows are preloaded into registers; the arm and pipe motor chains
 // commute (disjoint DOFs) and are interleaved for ILP; each contact is solved as an exact 3x3 Gauss-Seidel block: three
 // DPP row-reductions in flight at once, then the cross terms G bring dir1/dir2 up to date without touching `du`.
-template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P) {
+template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW& mw) {
   const int nc = sh.nc;
+  // early exit test without divisions: (dl / dinv)^2 <= resid  <=>  dl^2 - resid dinv^2 <= 0  for every row
 #ifdef PIH_HOST_EMUL
   real* du = sh.du;
   for (int d = 0; d < ND; d++) du[d] = 0;
   DofGeom geo[ND];
   for (int d = 0; d < ND; d++) geo[d] = dof_geom(sh, d);
   auto Wrow = [&](int row, int d) -> real {   // contact-row response entry for dof d
-    if (d >= 9) return sh.Wp[row][d - 9];
-    int ar = sh.c_arow[row / 3]; return ar >= 0 ? sh.Wa[3 * ar + row % 3][d] : (real)0;
+    if (d >= 9) return wp_row(sh, ov, row)[d - 9];
+    int ar = sh.c_arow[row / 3]; return ar >= 0 ? sh.b.Wa[3 * ar + row % 3][d] : (real)0;
   };
   for (int c = 0; c < nc; c++) { real l = sh.r_lam[3 * c]; if (l != 0) for (int d = 0; d < ND; d++) du[d] += Wrow(3 * c, d) * l; }
   int it = 0;
   for (; it < P.iters; it++) {
-    real res2 = 0;
+    real worst = -1;
+    auto track = [&](real dl, real di) { real v = dl * dl - P.resid * di * di; if (v > worst) worst = v; };
     for (int m = 0; m < NMOT; m++) {
       int d = m < 9 ? m : 15 + (m - 9);
       real dl = sh.m_rhs[m] - du[d] * sh.m_dinv[m], sum = sh.m_lam[m] + dl, lim = sh.m_maximp[m];
       if (sum < -lim) { dl = -lim - sh.m_lam[m]; sum = -lim; } else if (sum > lim) { dl = lim - sh.m_lam[m]; sum = lim; }
       sh.m_lam[m] = sum;
-      if (m < 9) for (int k = 0; k < 9; k++) du[k] += sh.Wma[m][k] * dl; else for (int k = 0; k < 29; k++) du[9 + k] += sh.Wmp[m - 9][k] * dl;
-      real rs = dl / sh.m_dinv[m]; if (rs * rs > res2) res2 = rs * rs;
+      if (m < 9) for (int k = 0; k < 9; k++) du[k] += sh.hWma[m][k] * dl; else for (int k = 0; k < 29; k++) du[9 + k] += sh.hWmp[m - 9][k] * dl;
+      track(dl, sh.m_dinv[m]);
       if (m < 9) for (int side = 0; side < 2; side++) {   // the joint's lower / upper limit rows follow its motor row
         int k = 2 * m + side; real sg = side ? (real)-1 : (real)1;
         real dl2 = sh.l_rhs[k] - sg * du[m] * sh.m_dinv[m], sum2 = sh.l_lam[k] + dl2;
         if (sum2 < 0) { dl2 = -sh.l_lam[k]; sum2 = 0; }
         sh.l_lam[k] = sum2;
-        for (int j = 0; j < 9; j++) du[j] += sg * sh.Wma[m][j] * dl2;
-        real rs2 = dl2 / sh.m_dinv[m]; if (rs2 * rs2 > res2) res2 = rs2 * rs2;
+        for (int j = 0; j < 9; j++) du[j] += sg * sh.hWma[m][j] * dl2;
+        track(dl2, sh.m_dinv[m]);
       }
     }
     for (int c = 0; c < nc; c++) {
-      if (sh.c_la[c] < 0) continue;
-      V3 p = ld3(sh.c_p[c]);
+      const real* R = crec_of(sh, ov, c);
+      V3 p = ld3(R);
       for (int k = 0; k < 3; k++) {
         int row = 3 * c + k;
         real lo = 0, hi = PIH_BIG;
-        if (k > 0) { real tot = sh.r_lam[3 * c]; if (!(tot > 0)) continue; hi = sh.c_mu[c] * tot; lo = -hi; }
-        V3 dir = ld3(sh.r_dir[row]);
+        if (k > 0) { real tot = sh.r_lam[3 * c]; if (!(tot > 0)) continue; hi = R[5] * tot; lo = -hi; }
+        V3 dir = ld3(R + 8 + 4 * k);
         real jd = 0;
         for (int d = 0; d < ND; d++) jd += jac_entry(geo[d], sh.c_la[c], sh.c_lb[c], p, dir) * du[d];
-        real dl = sh.r_rhs[row] - jd * sh.r_dinv[row], sum = sh.r_lam[row] + dl;
+        real di = R[11 + 4 * k];
+        real dl = R[20 + k] - jd * di, sum = sh.r_lam[row] + dl;
         if (sum < lo) { dl = lo - sh.r_lam[row]; sum = lo; } else if (sum > hi) { dl = hi - sh.r_lam[row]; sum = hi; }
         sh.r_lam[row] = sum;
         for (int d = 0; d < ND; d++) du[d] += Wrow(row, d) * dl;
-        real rs = dl / sh.r_dinv[row]; if (rs * rs > res2) res2 = rs * rs;
+        track(dl, di);
       }
     }
-    if (res2 <= P.resid) { it++; break; }
+    if (worst <= 0) { it++; break; }
   }
   for (int d = 0; d < ND; d++) sh.u[d] += du[d];
+  (void)mw;
   return it;
 #else
   w.sync();
@@ -928,38 +969,41 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P) {
   const bool armlane = d < 9, pipelane = d >= 9 && d < ND;
   // lane-distributed row state: motor m in lane m (m < 32), limit rows of arm joint j in lane j, contact c in lane c
   real m_di = d < NMOT ? sh.m_dinv[d] : (real)1, m_rhs = d < NMOT ? sh.m_rhs[d] : (real)0, m_lim = d < NMOT ? sh.m_maximp[d] : (real)0;
-  real m_wjj = (real)1 / m_di, m_lam = 0;
+  real m_lam = 0;
+  const real m_thr = P.resid * m_di * m_di;
   real lo_rhs = d < 9 ? sh.l_rhs[2 * d] : (real)0, hi_rhs = d < 9 ? sh.l_rhs[2 * d + 1] : (real)0, lo_lam = 0, hi_lam = 0;
+  real m_wjj = (real)1 / m_di;
   real cl0 = d < nc ? sh.r_lam[3 * d] : (real)0, cl1 = 0, cl2 = 0;
-  // motor response rows in registers: arm lanes hold column d of Wma, pipe lanes column d-9 of Wmp
-  real wreg[PIH_OBJ_NJ];
-#pragma unroll
-  for (int j = 0; j < PIH_OBJ_NJ; j++) wreg[j] = armlane ? (j < 9 ? sh.Wma[j][d] : (real)0) : (pipelane ? sh.Wmp[j][d - 9] : (real)0);
+  // per-lane sign of every contact's Jacobian column: bit c of ancA / ancB = this lane's joint is an ancestor of linkA / linkB
+  unsigned long long ancA = 0, ancB = 0;
   real du = 0;
-  for (int c = 0; c < nc; c++) {   // warm start
-    real l = rdlane(cl0, c);
-    if (l != 0) { int ar = sh.c_arow[c]; du += (pipelane ? sh.Wp[3 * c][d - 9] : (armlane && ar >= 0 ? sh.Wa[3 * ar][d] : (real)0)) * l; }
+  for (int c = 0; c < nc; c++) {
+    int la = sh.c_la[c], lb = sh.c_lb[c];
+    if (g.kind != 2 && is_anc(g.L, la)) ancA |= 1ull << c;
+    if (g.kind != 2 && is_anc(g.L, lb)) ancB |= 1ull << c;
+    real l = rdlane(cl0, c);   // warm start
+    if (l != 0) { int ar = sh.c_arow[c]; du += (pipelane ? wp_row(sh, ov, 3 * c)[d - 9] : (armlane && ar >= 0 ? sh.b.Wa[3 * ar][d] : (real)0)) * l; }
   }
   int it = 0;
   for (; it < P.iters; it++) {
-    real res2 = 0;
+    real worst = -1;
 #pragma unroll
     for (int j = 0; j < PIH_OBJ_NJ; j++) {
       real tot_a = 0;
       if (j < 9) {   // arm joint block: motor, lower limit, upper limit (wave-uniform scalar chain)
-        real dj = rdlane(du, j), di = rdlane(m_di, j), wjj = rdlane(m_wjj, j);
+        real dj = rdlane(du, j), di = rdlane(m_di, j), wjj = rdlane(m_wjj, j), thr = rdlane(m_thr, j);
         real lam = rdlane(m_lam, j), lim = rdlane(m_lim, j);
         real dl = rdlane(m_rhs, j) - dj * di, sum = lam + dl;
         sum = sum < -lim ? -lim : (sum > lim ? lim : sum); dl = sum - lam;
-        real r0 = dl * wjj; res2 = r0 * r0 > res2 ? r0 * r0 : res2;
+        real v0 = dl * dl - thr; worst = v0 > worst ? v0 : worst;
         dj += dl * wjj;
         real ll = rdlane(lo_lam, j), d2 = rdlane(lo_rhs, j) - dj * di, s2 = ll + d2;
         s2 = s2 < 0 ? (real)0 : s2; d2 = s2 - ll;
-        real r1 = d2 * wjj; res2 = r1 * r1 > res2 ? r1 * r1 : res2;
+        real v1 = d2 * d2 - thr; worst = v1 > worst ? v1 : worst;
         dj += d2 * wjj;
         real lh = rdlane(hi_lam, j), d3 = rdlane(hi_rhs, j) + dj * di, s3 = lh + d3;
         s3 = s3 < 0 ? (real)0 : s3; d3 = s3 - lh;
-        real r2 = d3 * wjj; res2 = r2 * r2 > res2 ? r2 * r2 : res2;
+        real v2 = d3 * d3 - thr; worst = v2 > worst ? v2 : worst;
         tot_a = dl + d2 - d3;
         if (d == j) { m_lam = sum; lo_lam = s2; hi_lam = s3; }
       }
@@ -967,22 +1011,22 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P) {
       real dj = rdlane(du, 15 + j), di = rdlane(m_di, 9 + j), lam = rdlane(m_lam, 9 + j), lim = rdlane(m_lim, 9 + j);
       real dl = rdlane(m_rhs, 9 + j) - dj * di, sum = lam + dl;
       sum = sum < -lim ? -lim : (sum > lim ? lim : sum); dl = sum - lam;
-      real rs = dl * rdlane(m_wjj, 9 + j); res2 = rs * rs > res2 ? rs * rs : res2;
+      real vp = dl * dl - rdlane(m_thr, 9 + j); worst = vp > worst ? vp : worst;
       if (d == 9 + j) m_lam = sum;
-      du += wreg[j] * (armlane ? tot_a : dl);
+      du += mw.w[j] * (armlane ? tot_a : dl);
     }
     for (int c = 0; c < nc; c++) {
-      const real* R = sh.crec[c];
-      const int la = (int)R[3], lb = (int)R[4], ar = (int)R[6];
+      const real* R = crec_of(sh, ov, c);
+      const int ar = (int)R[6];
       real w0 = 0, w1 = 0, w2 = 0;
-      if (pipelane) { w0 = sh.Wp[3 * c][d - 9]; w1 = sh.Wp[3 * c + 1][d - 9]; w2 = sh.Wp[3 * c + 2][d - 9]; }
-      else if (armlane && ar >= 0) { w0 = sh.Wa[3 * ar][d]; w1 = sh.Wa[3 * ar + 1][d]; w2 = sh.Wa[3 * ar + 2][d]; }
+      if (pipelane) { const real* wr = wp_row(sh, ov, 3 * c); w0 = wr[d - 9]; w1 = wr[WPS + d - 9]; w2 = wr[2 * WPS + d - 9]; }
+      else if (armlane && ar >= 0) { w0 = sh.b.Wa[3 * ar][d]; w1 = sh.b.Wa[3 * ar + 1][d]; w2 = sh.b.Wa[3 * ar + 2][d]; }
       const V3 p = mk(R[0], R[1], R[2]);
       const real mu = R[5];
       // Jacobian entries of this lane's DOF for the three directions share a x (p - o)
-      real sgn = (is_anc(g.L, la) ? (real)1 : (real)0) - (is_anc(g.L, lb) ? (real)1 : (real)0);
+      real sgn = (real)(int)((ancA >> c) & 1ull) - (real)(int)((ancB >> c) & 1ull);
       V3 cv = g.kind == 0 ? cross(g.a, p - g.o) : g.a;
-      real sdu = (g.kind == 2 ? (real)0 : sgn) * du;
+      real sdu = sgn * du;
       real x0 = sdu * dot(mk(R[8], R[9], R[10]), cv), x1 = sdu * dot(mk(R[12], R[13], R[14]), cv), x2 = sdu * dot(mk(R[16], R[17], R[18]), cv);
       row16_sum3(x0, x1, x2);
       real jd0 = rdlane(x0, 0) + rdlane(x0, 16) + rdlane(x0, 32);
@@ -992,21 +1036,21 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P) {
       real di0 = R[11], di1 = R[15], di2 = R[19];
       real dl0 = R[20] - jd0 * di0, s0 = l0 + dl0;
       s0 = s0 < 0 ? (real)0 : s0; dl0 = s0 - l0;
-      real rs0 = dl0 / di0; res2 = rs0 * rs0 > res2 ? rs0 * rs0 : res2;
+      real v0 = dl0 * dl0 - P.resid * di0 * di0; worst = v0 > worst ? v0 : worst;
       real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
       if (s0 > 0) {
         real hi = mu * s0;
         jd1 += R[23] * dl0;
         dl1 = R[21] - jd1 * di1; s1 = l1 + dl1; s1 = s1 < -hi ? -hi : (s1 > hi ? hi : s1); dl1 = s1 - l1;
-        real rs1 = dl1 / di1; res2 = rs1 * rs1 > res2 ? rs1 * rs1 : res2;
+        real v1 = dl1 * dl1 - P.resid * di1 * di1; worst = v1 > worst ? v1 : worst;
         jd2 += R[24] * dl0 + R[25] * dl1;
         dl2 = R[22] - jd2 * di2; s2 = l2 + dl2; s2 = s2 < -hi ? -hi : (s2 > hi ? hi : s2); dl2 = s2 - l2;
-        real rs2 = dl2 / di2; res2 = rs2 * rs2 > res2 ? rs2 * rs2 : res2;
+        real v2 = dl2 * dl2 - P.resid * di2 * di2; worst = v2 > worst ? v2 : worst;
       }
       if (d == c) { cl0 = s0; cl1 = s1; cl2 = s2; }
       du += w0 * dl0 + w1 * dl1 + w2 * dl2;
     }
-    if (res2 <= P.resid) { it++; break; }
+    if (worst <= 0) { it++; break; }
   }
   if (d < NMOT) sh.m_lam[d] = m_lam;
   if (d < 9) { sh.l_lam[2 * d] = lo_lam; sh.l_lam[2 * d + 1] = hi_lam; }
@@ -1026,7 +1070,7 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P) {
 #endif
 
 template <class W>
-PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* action, real* obs, real* reward, unsigned char* done, real* dbg) {
+PIH_HD void step_env(W& w, Shared& sh, const Params& P, const Ovf& ov, int env, const real* action, real* obs, real* reward, unsigned char* done, real* dbg) {
   real* S = sh.S;
   const real dt = P.dt;
 #ifndef PIH_HOST_EMUL
@@ -1056,14 +1100,15 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* act
         o[5] = sh.c_n[c][0]; o[6] = sh.c_n[c][1]; o[7] = sh.c_n[c][2]; o[8] = sh.c_depth[c]; o[9] = sh.c_mu[c]; o[10] = (real)sh.c_key[c];
       });
     }
-    build_rows(w, sh, P);
+    MotorW mw;
+    build_rows(w, sh, P, ov, mw);
     PIH_STAMP(4);
-    int iters = pgs(w, sh, P);
+    int iters = pgs(w, sh, P, ov, mw);
     PIH_STAMP(5);
     // integrate + bookkeeping
     w.par(ND, [&](int d) {
       real v = sh.u[d];
-      if (d < 9 || d >= 15) v = clampr(v, -PIH_MAX_COORD_VEL, PIH_MAX_COORD_VEL);
+      v = clampr(v, -PIH_MAX_COORD_VEL, PIH_MAX_COORD_VEL);   // Bullet m_maxCoordinateVelocity, floating base included
       if (d < 9) { S[PIH_S_QDARM + d] = v; S[PIH_S_QARM + d] += dt * v; }
       else if (d < 12) { S[PIH_S_VLIN + d - 9] = v; S[PIH_S_POS + d - 9] += dt * v; }
       else if (d < 15) S[PIH_S_VANG + d - 12] = v;
@@ -1090,7 +1135,7 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, int env, const real* act
     });
     if (dbg && P.debug) {
       w.par(sh.nc, [&](int c) { dbg[40 + 12 * c + 11] = sh.r_lam[3 * c]; });
-      w.par(3 * sh.nc, [&](int r) { dbg[640 + r] = sh.r_dinv[r]; });
+      w.par(3 * sh.nc, [&](int r) { dbg[640 + r] = crec_of(sh, ov, r / 3)[11 + 4 * (r % 3)]; });
     }
     S[PIH_S_CACHE_N] = (real)sh.nc;
     S[PIH_S_CFORCE] = cf / dt; S[PIH_S_NCONTACT] = (real)sh.nc; S[PIH_S_PGS_ITERS] = (real)iters;

@@ -13,9 +13,10 @@ using namespace pih;
 // ------------------------------------------------------------------------------------------------ kernels
 // state: float[n][256] (env-major records: the 64 lanes of the env's wave read/write consecutive words, so every
 // access is a fully coalesced 256 B segment).
-__global__ void __launch_bounds__(64) pih_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
+__global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
                                                       float* __restrict__ obs, float* __restrict__ reward,
-                                                      unsigned char* __restrict__ done, float* __restrict__ dbg) {
+                                                      unsigned char* __restrict__ done, float* __restrict__ dbg,
+                                                      float* __restrict__ ovf) {
   __shared__ Shared sh;
   const int env = blockIdx.x, lane = threadIdx.x;
   Wave w; w.l = lane; w.counter = 0;
@@ -26,7 +27,8 @@ __global__ void __launch_bounds__(64) pih_step_kernel(Params P, float* __restric
   float a[4] = {0, 0, 0, 0};
   if (actions) { a[0] = actions[env * 4]; a[1] = actions[env * 4 + 1]; a[2] = actions[env * 4 + 2]; a[3] = actions[env * 4 + 3]; }
   float o[5], r; unsigned char d;
-  step_env(w, sh, P, env, a, o, &r, &d, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
+  Ovf ov; ov.base = ovf + (size_t)env * OVF_WORDS;
+  step_env(w, sh, P, ov, env, a, o, &r, &d, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < PIH_STATE_WORDS / 64; i++) rec[lane + 64 * i] = sh.S[lane + 64 * i];
@@ -91,6 +93,7 @@ struct pih_handle {
   int device;
   float* state = nullptr;
   float* dbg = nullptr;
+  float* ovf = nullptr;     // spill area for contacts beyond the LDS-resident CL (rarely touched)
   std::string err;
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // event pairs bracketing each step launch
@@ -138,6 +141,7 @@ int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** ou
   size_t nb = (size_t)cfg->n_envs * PIH_STATE_WORDS * sizeof(float);
   HIPCHK(h, hipMalloc(&h->state, nb));
   HIPCHK(h, hipMemset(h->state, 0, nb));
+  HIPCHK(h, hipMalloc(&h->ovf, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
   if (cfg->debug) { HIPCHK(h, hipMalloc(&h->dbg, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); HIPCHK(h, hipMemset(h->dbg, 0, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); }
   float* offd = nullptr;
   if (offsets_host) {
@@ -158,6 +162,7 @@ int pih_destroy(pih_handle* h) {
   for (auto& p : h->ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   if (h->state) hipFree(h->state);
   if (h->dbg) hipFree(h->dbg);
+  if (h->ovf) hipFree(h->ovf);
   delete h;
   return 0;
 }
@@ -181,7 +186,7 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
     e0 = h->ev[h->ev_used].first; e1 = h->ev[h->ev_used].second; h->ev_used++;
     HIPCHK(h, hipEventRecord(e0, s));
   }
-  hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, actions, obs, reward, done, h->dbg);
+  hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->ovf);
   if (h->timing) HIPCHK(h, hipEventRecord(e1, s));
   HIPCHK(h, hipGetLastError());
   return 0;

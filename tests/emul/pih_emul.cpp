@@ -57,7 +57,9 @@ void emul_step(void* h, const double* actions, double* obs, double* reward, unsi
     real a[4], o[5], r; unsigned char d;
     for (int k = 0; k < 4; k++) a[k] = (real)actions[4 * i + k];
     Wave w;
-    step_env(w, sh, e->P, i, a, o, &r, &d, &e->dbg[(size_t)i * PIH_DEBUG_WORDS]);
+    static real ovfbuf[OVF_WORDS];
+    Ovf ov; ov.base = ovfbuf;
+    step_env(w, sh, e->P, ov, i, a, o, &r, &d, &e->dbg[(size_t)i * PIH_DEBUG_WORDS]);
     memcpy(S, sh.S, sizeof(real) * PIH_STATE_WORDS);
     for (int k = 0; k < 5; k++) obs[5 * i + k] = o[k];
     reward[i] = r; done[i] = d;
