@@ -114,7 +114,7 @@ constexpr int WMA_OFF = PIH_OBJ_NJ * WPS;   // word offset of Wma inside ArenaB:
 static_assert(WMA_OFF + 81 <= 3 * CL * WPS, "motor response rows must fit in the Wp region");
 
 struct Shared {
-  real S[PIH_STATE_WORDS];
+  alignas(16) real S[PIH_STATE_WORDS];
   real LO[NL][3], LA[NL][3];       // world link origins and joint axes
   real VW[NL][3], VV[NL][3];       // link angular velocity, velocity of the link-origin point
   real AU[NL][6], ADinv[NL], Au[NL], AR[NL][3];   // U = I^A S, 1/D, u, r = o_L - o_parent
@@ -124,8 +124,11 @@ struct Shared {
   real c_p[CMAX][3], c_n[CMAX][3], c_depth[CMAX], c_mu[CMAX];
   int nc, nca;
   real r_lam[NROWC];
-  real m_vt[NMOT], m_maximp[NMOT], m_dinv[NMOT], m_rhs[NMOT], m_lam[NMOT];
-  real l_rhs[NLIM], l_lam[NLIM];
+  // packed motor / limit rows (16-byte records => one broadcast ds_read_b128 per row in the PGS loop):
+  //   mrec[m] = {1/(J W), rhs, resid/(J W)^2 (early-exit threshold), max impulse} ; before build_rows [1] holds the target velocity
+  //   lrec[j] = {rhs lower, rhs upper, J W of arm joint j, -}
+  alignas(16) real mrec[NMOT][4];
+  alignas(16) real lrec[9][4];
   real ik_T[7][12];
   union { ArenaA a; ArenaB b; };
 #ifdef PIH_HOST_EMUL
@@ -405,7 +408,7 @@ template <class W> PIH_HD void controller(W& w, Shared& sh, const Params& P, con
     real vt = 0, imp = 1;
     if (m < 7) { if (posctl_arm) { vt = kp_arm * (S[PIH_S_TARGET + m] - S[PIH_S_QARM + m]) / P.dt; imp = imp_arm; } }
     else if (m < 9) { if (posctl_f) { vt = kp_f * (S[PIH_S_TARGET + m] - S[PIH_S_QARM + m]) / P.dt; imp = imp_f; } }
-    sh.m_vt[m] = vt; sh.m_maximp[m] = imp;
+    sh.mrec[m][1] = vt; sh.mrec[m][3] = imp;
   });
 }
 
@@ -798,7 +801,8 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
     real jw = response(sh, -1, -1, mk(0, 0, 0), mk(0, 0, 0), L, o);
     real di = (real)1 / jw;
     int d = link_dof(L);
-    sh.m_dinv[m] = di; sh.m_rhs[m] = (sh.m_vt[m] - sh.u[d]) * di; sh.m_lam[m] = 0;
+    sh.mrec[m][0] = di; sh.mrec[m][1] = (sh.mrec[m][1] - sh.u[d]) * di; sh.mrec[m][2] = P.resid * di * di;
+    if (m < 9) sh.lrec[m][2] = jw;
   });
   w.par(NLIM, [&](int k) {
     int L = k >> 1, side = k & 1;
@@ -806,7 +810,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
     real pen = side == 0 ? q - L_LO[L] : L_HI[L] - q;
     real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
     real sg = side == 0 ? (real)1 : (real)-1;
-    sh.l_rhs[k] = (vb - sg * sh.u[L]) * sh.m_dinv[L]; sh.l_lam[k] = 0;
+    sh.lrec[L][side] = (vb - sg * sh.u[L]) * sh.mrec[L][0];
   });
   // pull the motor rows out of the staging words before the contact rows overwrite them
 #ifdef PIH_HOST_EMUL
@@ -919,24 +923,27 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
     int ar = sh.c_arow[row / 3]; return ar >= 0 ? sh.b.Wa[3 * ar + row % 3][d] : (real)0;
   };
   for (int c = 0; c < nc; c++) { real l = sh.r_lam[3 * c]; if (l != 0) for (int d = 0; d < ND; d++) du[d] += Wrow(3 * c, d) * l; }
+  real mlam[NMOT], llam[NLIM];
+  for (int m = 0; m < NMOT; m++) mlam[m] = 0;
+  for (int k = 0; k < NLIM; k++) llam[k] = 0;
   int it = 0;
   for (; it < P.iters; it++) {
     real worst = -1;
     auto track = [&](real dl, real di) { real v = dl * dl - P.resid * di * di; if (v > worst) worst = v; };
     for (int m = 0; m < NMOT; m++) {
       int d = m < 9 ? m : 15 + (m - 9);
-      real dl = sh.m_rhs[m] - du[d] * sh.m_dinv[m], sum = sh.m_lam[m] + dl, lim = sh.m_maximp[m];
-      if (sum < -lim) { dl = -lim - sh.m_lam[m]; sum = -lim; } else if (sum > lim) { dl = lim - sh.m_lam[m]; sum = lim; }
-      sh.m_lam[m] = sum;
+      real dl = sh.mrec[m][1] - du[d] * sh.mrec[m][0], sum = mlam[m] + dl, lim = sh.mrec[m][3];
+      if (sum < -lim) { dl = -lim - mlam[m]; sum = -lim; } else if (sum > lim) { dl = lim - mlam[m]; sum = lim; }
+      mlam[m] = sum;
       if (m < 9) for (int k = 0; k < 9; k++) du[k] += sh.hWma[m][k] * dl; else for (int k = 0; k < 29; k++) du[9 + k] += sh.hWmp[m - 9][k] * dl;
-      track(dl, sh.m_dinv[m]);
+      track(dl, sh.mrec[m][0]);
       if (m < 9) for (int side = 0; side < 2; side++) {   // the joint's lower / upper limit rows follow its motor row
         int k = 2 * m + side; real sg = side ? (real)-1 : (real)1;
-        real dl2 = sh.l_rhs[k] - sg * du[m] * sh.m_dinv[m], sum2 = sh.l_lam[k] + dl2;
-        if (sum2 < 0) { dl2 = -sh.l_lam[k]; sum2 = 0; }
-        sh.l_lam[k] = sum2;
+        real dl2 = sh.lrec[m][side] - sg * du[m] * sh.mrec[m][0], sum2 = llam[k] + dl2;
+        if (sum2 < 0) { dl2 = -llam[k]; sum2 = 0; }
+        llam[k] = sum2;
         for (int j = 0; j < 9; j++) du[j] += sg * sh.hWma[m][j] * dl2;
-        track(dl2, sh.m_dinv[m]);
+        track(dl2, sh.mrec[m][0]);
       }
     }
     for (int c = 0; c < nc; c++) {
@@ -967,12 +974,13 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
   const int d = w.lane();
   const DofGeom g = dof_geom(sh, d);
   const bool armlane = d < 9, pipelane = d >= 9 && d < ND;
-  // lane-distributed row state: motor m in lane m (m < 32), limit rows of arm joint j in lane j, contact c in lane c
-  real m_di = d < NMOT ? sh.m_dinv[d] : (real)1, m_rhs = d < NMOT ? sh.m_rhs[d] : (real)0, m_lim = d < NMOT ? sh.m_maximp[d] : (real)0;
-  real m_lam = 0;
-  const real m_thr = P.resid * m_di * m_di;
-  real lo_rhs = d < 9 ? sh.l_rhs[2 * d] : (real)0, hi_rhs = d < 9 ? sh.l_rhs[2 * d + 1] : (real)0, lo_lam = 0, hi_lam = 0;
-  real m_wjj = (real)1 / m_di;
+  // motor / limit multipliers: wave-uniform values held in VGPRs (no readlane, no conditional write-back);
+  // contact multipliers: lane-distributed, contact c in lane c
+  real lam_p[PIH_OBJ_NJ], lam_a[9], lam_lo[9], lam_hi[9];
+#pragma unroll
+  for (int j = 0; j < PIH_OBJ_NJ; j++) lam_p[j] = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
   real cl0 = d < nc ? sh.r_lam[3 * d] : (real)0, cl1 = 0, cl2 = 0;
   // per-lane sign of every contact's Jacobian column: bit c of ancA / ancB = this lane's joint is an ancestor of linkA / linkB
   unsigned long long ancA = 0, ancB = 0;
@@ -987,32 +995,37 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
   int it = 0;
   for (; it < P.iters; it++) {
     real worst = -1;
+    // the row constants are re-read from LDS every iteration ON PURPOSE: without this compiler barrier LICM hoists all
+    // ~155 loop-invariant loads out of the iteration loop and spills them to scratch inside the hot loop
+    __asm__ volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < PIH_OBJ_NJ; j++) {
       real tot_a = 0;
-      if (j < 9) {   // arm joint block: motor, lower limit, upper limit (wave-uniform scalar chain)
-        real dj = rdlane(du, j), di = rdlane(m_di, j), wjj = rdlane(m_wjj, j), thr = rdlane(m_thr, j);
-        real lam = rdlane(m_lam, j), lim = rdlane(m_lim, j);
-        real dl = rdlane(m_rhs, j) - dj * di, sum = lam + dl;
-        sum = sum < -lim ? -lim : (sum > lim ? lim : sum); dl = sum - lam;
+      if (j < 9) {   // arm joint block: motor, lower limit, upper limit (wave-uniform chain; constants by LDS broadcast)
+        const real di = sh.mrec[j][0], rhs = sh.mrec[j][1], thr = sh.mrec[j][2], lim = sh.mrec[j][3];
+        const real lor = sh.lrec[j][0], hir = sh.lrec[j][1], wjj = sh.lrec[j][2];
+        real dj = rdlane(du, j);
+        real sum = lam_a[j] + (rhs - dj * di);
+        sum = sum < -lim ? -lim : (sum > lim ? lim : sum);
+        real dl = sum - lam_a[j]; lam_a[j] = sum;
         real v0 = dl * dl - thr; worst = v0 > worst ? v0 : worst;
         dj += dl * wjj;
-        real ll = rdlane(lo_lam, j), d2 = rdlane(lo_rhs, j) - dj * di, s2 = ll + d2;
-        s2 = s2 < 0 ? (real)0 : s2; d2 = s2 - ll;
+        real s2 = lam_lo[j] + (lor - dj * di); s2 = s2 < 0 ? (real)0 : s2;
+        real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
         real v1 = d2 * d2 - thr; worst = v1 > worst ? v1 : worst;
         dj += d2 * wjj;
-        real lh = rdlane(hi_lam, j), d3 = rdlane(hi_rhs, j) + dj * di, s3 = lh + d3;
-        s3 = s3 < 0 ? (real)0 : s3; d3 = s3 - lh;
+        real s3 = lam_hi[j] + (hir + dj * di); s3 = s3 < 0 ? (real)0 : s3;
+        real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
         real v2 = d3 * d3 - thr; worst = v2 > worst ? v2 : worst;
         tot_a = dl + d2 - d3;
-        if (d == j) { m_lam = sum; lo_lam = s2; hi_lam = s3; }
       }
-      // pipe joint motor j (lane 9 + j holds its state; its DOF is 15 + j)
-      real dj = rdlane(du, 15 + j), di = rdlane(m_di, 9 + j), lam = rdlane(m_lam, 9 + j), lim = rdlane(m_lim, 9 + j);
-      real dl = rdlane(m_rhs, 9 + j) - dj * di, sum = lam + dl;
-      sum = sum < -lim ? -lim : (sum > lim ? lim : sum); dl = sum - lam;
-      real vp = dl * dl - rdlane(m_thr, 9 + j); worst = vp > worst ? vp : worst;
-      if (d == 9 + j) m_lam = sum;
+      // pipe joint motor j (DOF 15 + j)
+      const real di = sh.mrec[9 + j][0], rhs = sh.mrec[9 + j][1], thr = sh.mrec[9 + j][2], lim = sh.mrec[9 + j][3];
+      real dj = rdlane(du, 15 + j);
+      real sum = lam_p[j] + (rhs - dj * di);
+      sum = sum < -lim ? -lim : (sum > lim ? lim : sum);
+      real dl = sum - lam_p[j]; lam_p[j] = sum;
+      real vp = dl * dl - thr; worst = vp > worst ? vp : worst;
       du += mw.w[j] * (armlane ? tot_a : dl);
     }
     for (int c = 0; c < nc; c++) {
@@ -1052,8 +1065,6 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
     }
     if (worst <= 0) { it++; break; }
   }
-  if (d < NMOT) sh.m_lam[d] = m_lam;
-  if (d < 9) { sh.l_lam[2 * d] = lo_lam; sh.l_lam[2 * d + 1] = hi_lam; }
   if (d < nc) { sh.r_lam[3 * d] = cl0; sh.r_lam[3 * d + 1] = cl1; sh.r_lam[3 * d + 2] = cl2; }
   if (d < ND) sh.u[d] += du;
   w.sync();

@@ -10,11 +10,14 @@
 #endif
 typedef PIH_REAL real;
 #define PIH_HD inline
+#define PIH_NOINL inline
 #define PIH_CONST static const
 #else
 #include <hip/hip_runtime.h>
 typedef float real;
 #define PIH_HD __device__ __forceinline__
+// (measured: a non-inlined phase loses the LDS address space of `Shared&` and falls back to flat loads: 45 % slower PGS)
+#define PIH_NOINL __device__ __attribute__((noinline))
 #define PIH_CONST static __device__ __constant__ const
 #endif
 
