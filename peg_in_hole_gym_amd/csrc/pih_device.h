@@ -990,7 +990,13 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
     if (g.kind != 2 && is_anc(g.L, la)) ancA |= 1ull << c;
     if (g.kind != 2 && is_anc(g.L, lb)) ancB |= 1ull << c;
     real l = rdlane(cl0, c);   // warm start
-    if (l != 0) { int ar = sh.c_arow[c]; du += (pipelane ? wp_row(sh, ov, 3 * c)[d - 9] : (armlane && ar >= 0 ? sh.b.Wa[3 * ar][d] : (real)0)) * l; }
+    if (l != 0) {
+      int ar = sh.c_arow[c];
+      real wv = 0;
+      if (pipelane) wv = c < CL ? sh.b.Wp[3 * c][d - 9] : ov.base[(size_t)(3 * (c - CL)) * WPS + d - 9];
+      else if (armlane && ar >= 0) wv = sh.b.Wa[3 * ar][d];
+      du += wv * l;
+    }
   }
   int it = 0;
   for (; it < P.iters; it++) {
@@ -1028,11 +1034,13 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       real vp = dl * dl - thr; worst = vp > worst ? vp : worst;
       du += mw.w[j] * (armlane ? tot_a : dl);
     }
-    for (int c = 0; c < nc; c++) {
-      const real* R = crec_of(sh, ov, c);
+    // one exact 3x3 Gauss-Seidel block per contact.  The body is instantiated twice so that the LDS-resident contacts
+    // (c < CL) compile to ds_read with immediate offsets and only the rare spilled ones (c >= CL) use global loads; a
+    // single loop over "LDS or global" pointers degrades every access to flat_load + vmcnt(0)/lgkmcnt(0) waits.
+    auto block = [&](int c, const real* R, const real* wr) __attribute__((always_inline)) {
       const int ar = (int)R[6];
       real w0 = 0, w1 = 0, w2 = 0;
-      if (pipelane) { const real* wr = wp_row(sh, ov, 3 * c); w0 = wr[d - 9]; w1 = wr[WPS + d - 9]; w2 = wr[2 * WPS + d - 9]; }
+      if (pipelane) { w0 = wr[d - 9]; w1 = wr[WPS + d - 9]; w2 = wr[2 * WPS + d - 9]; }
       else if (armlane && ar >= 0) { w0 = sh.b.Wa[3 * ar][d]; w1 = sh.b.Wa[3 * ar + 1][d]; w2 = sh.b.Wa[3 * ar + 2][d]; }
       const V3 p = mk(R[0], R[1], R[2]);
       const real mu = R[5];
@@ -1062,7 +1070,10 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       }
       if (d == c) { cl0 = s0; cl1 = s1; cl2 = s2; }
       du += w0 * dl0 + w1 * dl1 + w2 * dl2;
-    }
+    };
+    const int ncl = nc < CL ? nc : CL;
+    for (int c = 0; c < ncl; c++) block(c, sh.b.crec[c], &sh.b.Wp[3 * c][0]);
+    for (int c = CL; c < nc; c++) block(c, ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC, ov.base + (size_t)(3 * (c - CL)) * WPS);
     if (worst <= 0) { it++; break; }
   }
   if (d < nc) { sh.r_lam[3 * d] = cl0; sh.r_lam[3 * d + 1] = cl1; sh.r_lam[3 * d + 2] = cl2; }
