@@ -108,7 +108,7 @@ struct ArenaB {
   // same words first and pulled into registers before the contact rows overwrite them
   real Wp[3 * CL][WPS];
   real Wa[3 * CAMAX][9];
-  real crec[CL][CREC];
+  alignas(16) real crec[CL][CREC];
 };
 constexpr int WMA_OFF = PIH_OBJ_NJ * WPS;   // word offset of Wma inside ArenaB::Wp
 static_assert(WMA_OFF + 81 <= 3 * CL * WPS, "motor response rows must fit in the Wp region");
@@ -859,6 +859,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
     real* R = crec_of(sh, ov, c);
     V3 t1 = ld3(R + 12), t2 = ld3(R + 16), dn = ld3(R + 26), d1 = ld3(R + 29);
     R[23] = dot(t1, dn); R[24] = dot(t2, dn); R[25] = dot(t2, d1);
+    R[26] = sh.r_lam[3 * c]; R[27] = 0; R[28] = 0;   // multipliers (n, t1, t2) live in the record from here on (GPU PGS)
   });
 }
 
@@ -894,6 +895,15 @@ PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane mus
 }
 template <int CTRL> PIH_HD real dpp_add(real x) {   // x + x[dpp-permuted lane]  (v_add_f32_dpp)
   return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL, int ROWMASK> PIH_HD real dpp_add_rows(real x) {   // rows in ROWMASK: x += dpp-source lane ; others unchanged
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, false));
+}
+// after row16_sum3: rows 1,3 += lane 15 of the previous row (row_bcast:15), rows 2,3 += lane 31 (row_bcast:31)
+// => lanes 32..47 hold the sum over lanes 0..47 (all 38 DOF lanes)
+PIH_HD void rows012_total3(real& a, real& b, real& c) {
+  a = dpp_add_rows<0x142, 0xA>(a); b = dpp_add_rows<0x142, 0xA>(b); c = dpp_add_rows<0x142, 0xA>(c);
+  a = dpp_add_rows<0x143, 0xC>(a); b = dpp_add_rows<0x143, 0xC>(b); c = dpp_add_rows<0x143, 0xC>(c);
 }
 // after this every lane holds the sum over its 16-lane row; three independent reductions interleaved for ILP
 PIH_HD void row16_sum3(real& a, real& b, real& c) {
@@ -981,7 +991,6 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
   for (int j = 0; j < PIH_OBJ_NJ; j++) lam_p[j] = 0;
 #pragma unroll
   for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
-  real cl0 = d < nc ? sh.r_lam[3 * d] : (real)0, cl1 = 0, cl2 = 0;
   // per-lane sign of every contact's Jacobian column: bit c of ancA / ancB = this lane's joint is an ancestor of linkA / linkB
   unsigned long long ancA = 0, ancB = 0;
   real du = 0;
@@ -989,7 +998,7 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
     int la = sh.c_la[c], lb = sh.c_lb[c];
     if (g.kind != 2 && is_anc(g.L, la)) ancA |= 1ull << c;
     if (g.kind != 2 && is_anc(g.L, lb)) ancB |= 1ull << c;
-    real l = rdlane(cl0, c);   // warm start
+    real l = sh.r_lam[3 * c];   // warm start (uniform LDS read)
     if (l != 0) {
       int ar = sh.c_arow[c];
       real wv = 0;
@@ -1012,71 +1021,98 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
         const real lor = sh.lrec[j][0], hir = sh.lrec[j][1], wjj = sh.lrec[j][2];
         real dj = rdlane(du, j);
         real sum = lam_a[j] + (rhs - dj * di);
-        sum = sum < -lim ? -lim : (sum > lim ? lim : sum);
+        sum = med3_(sum, -lim, lim);
         real dl = sum - lam_a[j]; lam_a[j] = sum;
-        real v0 = dl * dl - thr; worst = v0 > worst ? v0 : worst;
+        worst = max_(worst, dl * dl - thr);
         dj += dl * wjj;
-        real s2 = lam_lo[j] + (lor - dj * di); s2 = s2 < 0 ? (real)0 : s2;
+        real s2 = lam_lo[j] + (lor - dj * di); s2 = max_(s2, (real)0);
         real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
-        real v1 = d2 * d2 - thr; worst = v1 > worst ? v1 : worst;
+        worst = max_(worst, d2 * d2 - thr);
         dj += d2 * wjj;
-        real s3 = lam_hi[j] + (hir + dj * di); s3 = s3 < 0 ? (real)0 : s3;
+        real s3 = lam_hi[j] + (hir + dj * di); s3 = max_(s3, (real)0);
         real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
-        real v2 = d3 * d3 - thr; worst = v2 > worst ? v2 : worst;
+        worst = max_(worst, d3 * d3 - thr);
         tot_a = dl + d2 - d3;
       }
       // pipe joint motor j (DOF 15 + j)
       const real di = sh.mrec[9 + j][0], rhs = sh.mrec[9 + j][1], thr = sh.mrec[9 + j][2], lim = sh.mrec[9 + j][3];
       real dj = rdlane(du, 15 + j);
       real sum = lam_p[j] + (rhs - dj * di);
-      sum = sum < -lim ? -lim : (sum > lim ? lim : sum);
+      sum = med3_(sum, -lim, lim);
       real dl = sum - lam_p[j]; lam_p[j] = sum;
-      real vp = dl * dl - thr; worst = vp > worst ? vp : worst;
+      worst = max_(worst, dl * dl - thr);
       du += mw.w[j] * (armlane ? tot_a : dl);
     }
     // one exact 3x3 Gauss-Seidel block per contact.  The body is instantiated twice so that the LDS-resident contacts
     // (c < CL) compile to ds_read with immediate offsets and only the rare spilled ones (c >= CL) use global loads; a
     // single loop over "LDS or global" pointers degrades every access to flat_load + vmcnt(0)/lgkmcnt(0) waits.
-    auto block = [&](int c, const real* R, const real* wr) __attribute__((always_inline)) {
-      const int ar = (int)R[6];
-      real w0 = 0, w1 = 0, w2 = 0;
-      if (pipelane) { w0 = wr[d - 9]; w1 = wr[WPS + d - 9]; w2 = wr[2 * WPS + d - 9]; }
-      else if (armlane && ar >= 0) { w0 = sh.b.Wa[3 * ar][d]; w1 = sh.b.Wa[3 * ar + 1][d]; w2 = sh.b.Wa[3 * ar + 2][d]; }
-      const V3 p = mk(R[0], R[1], R[2]);
-      const real mu = R[5];
-      // Jacobian entries of this lane's DOF for the three directions share a x (p - o)
+    real worstc = -1;
+    // Whole record (8 x 16 B) + the three response-row entries of this lane are fetched in ONE batch, and for the
+    // LDS-resident contacts the next contact's batch is issued before the current block computes (software pipelining):
+    // piecemeal loads cost four serial LDS round trips per contact, which two waves per SIMD cannot hide.
+    struct CRec { real4 q[8]; real w0, w1, w2; };
+    auto fetch = [&](const real* R, const real* wr) __attribute__((always_inline)) -> CRec {
+      CRec r;
+#pragma unroll
+      for (int i = 0; i < 8; i++) r.q[i] = reinterpret_cast<const real4*>(R)[i];
+      r.w0 = 0; r.w1 = 0; r.w2 = 0;
+      if (pipelane) { r.w0 = wr[d - 9]; r.w1 = wr[WPS + d - 9]; r.w2 = wr[2 * WPS + d - 9]; }
+      return r;
+    };
+    auto block = [&](int c, const CRec& r, real* R, bool in_lds) __attribute__((always_inline)) {
+      // q0 = p.xyz, linkA | q1 = linkB, mu, arow, - | q2 = n, dinv_n | q3 = t1, dinv_t1 | q4 = t2, dinv_t2
+      // q5 = rhs n,t1,t2, G[t1][n] | q6 = G[t2][n], G[t2][t1], lam_n, lam_t1 | q7 = lam_t2, ...
+      real w0 = r.w0, w1 = r.w1, w2 = r.w2;
+      const int ar = (int)r.q[1].z;
+      if (armlane && ar >= 0) { w0 = sh.b.Wa[3 * ar][d]; w1 = sh.b.Wa[3 * ar + 1][d]; w2 = sh.b.Wa[3 * ar + 2][d]; }
+      const V3 p = mk(r.q[0].x, r.q[0].y, r.q[0].z);
+      const real mu = r.q[1].y;
       real sgn = (real)(int)((ancA >> c) & 1ull) - (real)(int)((ancB >> c) & 1ull);
       V3 cv = g.kind == 0 ? cross(g.a, p - g.o) : g.a;
       real sdu = sgn * du;
-      real x0 = sdu * dot(mk(R[8], R[9], R[10]), cv), x1 = sdu * dot(mk(R[12], R[13], R[14]), cv), x2 = sdu * dot(mk(R[16], R[17], R[18]), cv);
-      row16_sum3(x0, x1, x2);
-      real jd0 = rdlane(x0, 0) + rdlane(x0, 16) + rdlane(x0, 32);
-      real jd1 = rdlane(x1, 0) + rdlane(x1, 16) + rdlane(x1, 32);
-      real jd2 = rdlane(x2, 0) + rdlane(x2, 16) + rdlane(x2, 32);
-      real l0 = rdlane(cl0, c), l1 = rdlane(cl1, c), l2 = rdlane(cl2, c);
-      real di0 = R[11], di1 = R[15], di2 = R[19];
-      real dl0 = R[20] - jd0 * di0, s0 = l0 + dl0;
-      s0 = s0 < 0 ? (real)0 : s0; dl0 = s0 - l0;
-      real v0 = dl0 * dl0 - P.resid * di0 * di0; worst = v0 > worst ? v0 : worst;
+      real jd0 = sdu * dot(mk(r.q[2].x, r.q[2].y, r.q[2].z), cv), jd1 = sdu * dot(mk(r.q[3].x, r.q[3].y, r.q[3].z), cv), jd2 = sdu * dot(mk(r.q[4].x, r.q[4].y, r.q[4].z), cv);
+      row16_sum3(jd0, jd1, jd2);
+      rows012_total3(jd0, jd1, jd2);          // valid in lanes 32..47 from here; the scalar chain below runs in plain VGPRs
+      const real l0 = r.q[6].z, l1 = r.q[6].w, l2 = r.q[7].x;
+      const real di0 = r.q[2].w, di1 = r.q[3].w, di2 = r.q[4].w;
+      real s0 = l0 + (r.q[5].x - jd0 * di0);
+      s0 = max_(s0, (real)0);
+      real dl0 = s0 - l0;
+      worstc = max_(worstc, dl0 * dl0 - P.resid * di0 * di0);
       real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
-      if (s0 > 0) {
+      if (rdlane(s0, 32) > 0) {               // wave-uniform branch
         real hi = mu * s0;
-        jd1 += R[23] * dl0;
-        dl1 = R[21] - jd1 * di1; s1 = l1 + dl1; s1 = s1 < -hi ? -hi : (s1 > hi ? hi : s1); dl1 = s1 - l1;
-        real v1 = dl1 * dl1 - P.resid * di1 * di1; worst = v1 > worst ? v1 : worst;
-        jd2 += R[24] * dl0 + R[25] * dl1;
-        dl2 = R[22] - jd2 * di2; s2 = l2 + dl2; s2 = s2 < -hi ? -hi : (s2 > hi ? hi : s2); dl2 = s2 - l2;
-        real v2 = dl2 * dl2 - P.resid * di2 * di2; worst = v2 > worst ? v2 : worst;
+        jd1 += r.q[5].w * dl0;
+        s1 = l1 + (r.q[5].y - jd1 * di1); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
+        worstc = max_(worstc, dl1 * dl1 - P.resid * di1 * di1);
+        jd2 += r.q[6].x * dl0 + r.q[6].y * dl1;
+        s2 = l2 + (r.q[5].z - jd2 * di2); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
+        worstc = max_(worstc, dl2 * dl2 - P.resid * di2 * di2);
       }
-      if (d == c) { cl0 = s0; cl1 = s1; cl2 = s2; }
-      du += w0 * dl0 + w1 * dl1 + w2 * dl2;
+      if (d == 32) { R[26] = s0; R[27] = s1; R[28] = s2; }
+      if (!in_lds) __threadfence_block();     // spilled records live in global memory: make lane 32's store visible to the wave
+      du += w0 * rdlane(dl0, 32) + w1 * rdlane(dl1, 32) + w2 * rdlane(dl2, 32);
     };
     const int ncl = nc < CL ? nc : CL;
-    for (int c = 0; c < ncl; c++) block(c, sh.b.crec[c], &sh.b.Wp[3 * c][0]);
-    for (int c = CL; c < nc; c++) block(c, ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC, ov.base + (size_t)(3 * (c - CL)) * WPS);
+    if (ncl > 0) {
+      CRec cur = fetch(sh.b.crec[0], &sh.b.Wp[0][0]);
+      for (int c = 0; c < ncl; c++) {
+        const int cn = c + 1 < ncl ? c + 1 : c;
+        CRec nxt = fetch(sh.b.crec[cn], &sh.b.Wp[3 * cn][0]);
+        block(c, cur, sh.b.crec[c], true);
+        cur = nxt;
+      }
+    }
+    for (int c = CL; c < nc; c++) {
+      real* R = ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC;
+      CRec r = fetch(R, ov.base + (size_t)(3 * (c - CL)) * WPS);
+      block(c, r, R, false);
+    }
+    worst = max_(worst, rdlane(worstc, 32));
     if (worst <= 0) { it++; break; }
   }
-  if (d < nc) { sh.r_lam[3 * d] = cl0; sh.r_lam[3 * d + 1] = cl1; sh.r_lam[3 * d + 2] = cl2; }
+  w.sync();
+  if (d < nc) { const real* R = d < CL ? sh.b.crec[d] : ov.base + OVF_W_WORDS + (size_t)(d - CL) * CREC; sh.r_lam[3 * d] = R[26]; sh.r_lam[3 * d + 1] = R[27]; sh.r_lam[3 * d + 2] = R[28]; }
   if (d < ND) sh.u[d] += du;
   w.sync();
   return it;

@@ -24,6 +24,7 @@ typedef float real;
 namespace pih {
 
 struct V3 { real x, y, z; };
+struct alignas(16) real4 { real x, y, z, w; };
 PIH_HD V3 mk(real x, real y, real z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 PIH_HD V3 ld3(const real* p) { return mk(p[0], p[1], p[2]); }
 PIH_HD void st3(real* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
@@ -38,6 +39,14 @@ PIH_HD real rsqrt_(real x) { return (real)1 / (real)sqrt(x); }
 PIH_HD real norm(V3 a) { return (real)sqrt(dot(a, a)); }
 PIH_HD real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 PIH_HD real absr(real x) { return x < 0 ? -x : x; }
+// single-instruction clamp / max on the GPU (v_med3_f32 / v_max_f32); the ?: forms compile to cmp + cndmask pairs
+#ifdef PIH_HOST_EMUL
+PIH_HD real med3_(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+PIH_HD real max_(real a, real b) { return a > b ? a : b; }
+#else
+PIH_HD real med3_(real x, real lo, real hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+PIH_HD real max_(real a, real b) { return __builtin_fmaxf(a, b); }
+#endif
 
 #ifdef PIH_HOST_EMUL
 PIH_HD void sincos_(double a, double* s, double* c) { *s = sin(a); *c = cos(a); }
