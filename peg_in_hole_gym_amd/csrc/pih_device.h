@@ -60,7 +60,9 @@ PIH_CONST int SAMP_LINK[NSAMP] = PIH_PIPE_SAMP_LINK;
 PIH_CONST real SAMP_Y[NSAMP] = PIH_PIPE_SAMP_Y;
 PIH_CONST int SAMP_VERTEX[NSAMP] = PIH_PIPE_SAMP_VERTEX;
 PIH_CONST real HOLE_POS[3] = PIH_HOLE_POS;
-PIH_CONST real FSM_DUR[10] = {0.25, 2, 2, 1, 1.5, 1.5, 0.5, 0.25, 0.25, 0.25};   // envs/peg_in_hole.py:263
+// envs/peg_in_hole.py:206-212,263: the reference's clock `t += 1/240; if t > dur[s]` evaluated in fp64 fires after exactly
+// FSM_STEPS[s] calls; the device counts steps (fp32 accumulation of 1/240 would fire one step late in some states)
+PIH_CONST int FSM_STEPS[10] = PIH_FSM_STEPS;
 
 #define PIH_PI ((real)3.14159265358979323846)
 #define PIH_LIN_DAMP ((real)0.04)
@@ -371,9 +373,9 @@ template <class W> PIH_HD void controller(W& w, Shared& sh, const Params& P, con
   } else {
     // random_grasp loop body, envs/peg_in_hole.py:53-112 (update_state :206-212, grasp_process :122-204)
     int st = (int)S[PIH_S_FSM];
-    real t = S[PIH_S_FSMT] + P.dt;
-    if (t > FSM_DUR[st]) { st += 1; t = 0; if (st >= 10) st = 0; }
-    S[PIH_S_FSM] = (real)st; S[PIH_S_FSMT] = t;
+    int nstep = (int)(S[PIH_S_FSMT] * (real)240 + (real)0.5) + 1;      // S[FSMT] holds the state clock in seconds, as the reference does
+    if (nstep >= FSM_STEPS[st]) { st += 1; nstep = 0; if (st >= 10) st = 0; }
+    S[PIH_S_FSM] = (real)st; S[PIH_S_FSMT] = (real)nstep * (real)(1.0 / 240.0);
     real tip[7]; tip_pose(sh, tip);
     Q4 tornq; tornq.x = tip[3]; tornq.y = tip[4]; tornq.z = tip[5]; tornq.w = tip[6];
     V3 rv = mul(q_to_m(tornq), mk(0, S[PIH_S_RANDY], 0));

@@ -186,3 +186,40 @@ def test_full_size_properties(torch_mod):
         assert st[:, 97].sum().item() == 0                   # no env was ever reset because of a non-finite state
         assert (st[:, 20] > -0.2).all()                 # nothing tunnelled through the table
     assert torch.equal(outs[0], outs[1])
+
+
+def test_scripted_mode_on_gpu(torch_mod, oracle_mod):
+    """Scripted episodes (reference step() semantics) on the GPU: exact FSM clock, done after 2226 env-steps, and
+    resynchronised one-step parity with the oracle through approach / descent / finger closing."""
+    torch = torch_mod
+    N = 8
+    kw = dict(mode=1, dv=0.05, residual_threshold=0.0, warmstart=0.0)
+    g = _gpu(N, **kw)
+    g.step_n(2225)
+    torch.cuda.synchronize()
+    st = g.state().cpu().numpy()
+    assert (st[:, 86] == 8).all() and not g.done.cpu().numpy().any()
+    g.step_n(1)
+    st = g.state().cpu().numpy()
+    assert (st[:, 86] == 9).all() and (st[:, 93] == 2226).all() and g.done.cpu().numpy().all()
+    assert np.isfinite(st).all()
+
+    o = oracle_mod.Oracle(N, **kw)
+    g2 = _gpu(N, **kw)
+    a = np.zeros((N, 4)); at = torch.zeros(N, 4)
+    errs = []
+    for t in range(1150):
+        check = t < 100 or 560 <= t < 660 or 1020 <= t < 1150
+        if check:
+            _to_gpu_state(torch, g2, o.get_state())
+        o.step(a)
+        if check:
+            g2.step(at)
+            so = o.get_state(); sg = g2.state().cpu().numpy().astype(np.float64)
+            np.testing.assert_array_equal(so[:, 86], sg[:, 86])
+            np.testing.assert_array_equal(o.ncontacts(), sg[:, 106].astype(int))
+            np.testing.assert_allclose(so[:, 77:86], sg[:, 77:86], atol=2e-4)
+            errs.append(np.abs(so[:, POS] - sg[:, POS]).max(1))
+    errs = np.concatenate(errs)
+    print("scripted one-step pose err p50/p99/max = %.2e / %.2e / %.2e" % (np.percentile(errs, 50), np.percentile(errs, 99), errs.max()))
+    assert np.percentile(errs, 50) < 5e-6 and np.percentile(errs, 99) < 5e-4

@@ -195,4 +195,17 @@ print("#define PIH_HOLE_RIN %s   /* 0.96 * 0.016 */" % fmt(0.96 * 0.016))
 print("#define PIH_HOLE_ROUT %s  /* 1.2 * 0.016 */" % fmt(1.2 * 0.016))
 print("#define PIH_HOLE_MU 0.5")
 print("#define PIH_GRAVITY_Z (-9.8)  /* envs/peg_in_hole.py:230 */")
+# scripted FSM clock (envs/peg_in_hole.py:206-212,254,263): number of update_state() calls spent in each state before the
+# transition fires, obtained by replaying the reference's own double-precision arithmetic `t += 1/240; if t > dur: ...`
+durs = [0.25, 2, 2, 1, 1.5, 1.5, 0.5, 0.25, 0.25, 0.25]
+fsm_steps = []
+for dur in durs:
+    t, k = 0.0, 0
+    while True:
+        t += 1.0 / 240
+        k += 1
+        if t > dur:
+            break
+    fsm_steps.append(k)
+print("#define PIH_FSM_STEPS " + iarr(fsm_steps) + "  /* update_state() calls per FSM state (exact replay of the fp64 clock) */")
 print("#endif")
