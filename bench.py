@@ -29,6 +29,20 @@ FLOP_PER_ENV_STEP_EST = 1.4e6         # SURVEY.md 8d estimate (reported as conte
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 
 
+def pmc_traffic(n_envs):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/pmc_latest.json, produced by
+    tools/pmc_traffic.sh in separate --pmc passes): counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        d = json.load(open(path))
+        if d.get("n_envs") == n_envs and d.get("traffic_raw"):
+            return d["traffic_raw"], {"fetch_size_kib": d["fetch_size_kib"], "write_size_kib": d["write_size_kib"],
+                                      "fetch_x2_variant": d["traffic_fetch_x2"], "source": "profiles/pmc_latest.json (%s)" % d.get("tag")}
+    except Exception:  # noqa: BLE001
+        pass
+    return None, None
+
+
 def cpu_baseline(envs_sample=256, steps=40):
     """Oracle ("port") on the host cores, all threads, bounded sample: envs_sample envs x steps steps."""
     import numpy as np
@@ -119,6 +133,7 @@ def main():
         total_envs = n * world
         value = total_envs * args.steps / elapsed
         achieved = ALG_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic, traffic_detail = pmc_traffic(n)
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -126,7 +141,8 @@ def main():
             "config": {"workload": "Panda peg-in-hole, %d parallel envs per GPU, random actions U(-1,1), dt=1/240, auto-reset" % n,
                        "envs_per_gpu": n, "total_envs": total_envs, "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + RCCL all-gather(obs)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "pih_step_kernel", "kernel_avg_ms": kernel_ms, "launches": launches,
+                         "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (ALG_BYTES_PER_ENV_STEP * n),
+                         "kernel": "pih_step_kernel", "kernel_avg_ms": kernel_ms, "launches": launches,
                          "alg_bytes_per_env_step": ALG_BYTES_PER_ENV_STEP,
                          "note": "latency/VALU/LDS-bound path (SURVEY.md 0.6): HBM fraction is ~0 by construction; "
                                  "est. %.2f TFLOP/s = %.2f%% of fp32 vector peak" % (FLOP_PER_ENV_STEP_EST * n / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0,

@@ -9,7 +9,8 @@
  *                           (envs/utils.py:60-68), p.getLinkState (envs/utils.py:62, envs/peg_in_hole.py:58,115,123)
  *                           and the Python multiprocessing scatter/gather of envs/base_env_mp.py:40-51,75-87
  *   pih_reset     replaces  envs/base_env.py:84-94 + envs/peg_in_hole.py:227-274 (loadURDF/resetJointState scene build)
- *   pih_ik        replaces  p.calculateInverseKinematics stand-alone (envs/utils.py:67,79; envs/meta_env.py:92,104)
+ *   pih_ik / pih_ik_ur5  replace  p.calculateInverseKinematics stand-alone for the Panda / UR5 chain
+ *                           (envs/utils.py:67,79; envs/meta_env.py:92,104)
  *   pih_get_state replaces  p.getLinkState / p.getJointState / (north_star) getContactPoints normal force read-backs
  *
  * Conventions: every call returns 0 on success, <0 on error (pih_last_error gives the text).  All *_dev pointers
@@ -96,6 +97,8 @@ int pih_get_state(pih_handle* h, int field, void* out_dev, void* stream);
 int pih_set_state(pih_handle* h, int field, const void* in_dev, void* stream);
 /* stand-alone batched IK: q0 float[n,9], tpos float[n,3], tquat float[n,4] (xyzw) -> qout float[n,9] */
 int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream);
+/* the same for the UR5 chain of envs/assets/urdf/ur5.urdf (ur_execute, envs/utils.py:70-82): q0/qout float[n,6] */
+int pih_ik_ur5(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream);
 /* kernel timing with HIP events on `stream`: average ms per pih_step launch since the last call with reset=1 */
 int pih_timing(pih_handle* h, int reset, double* avg_ms_out, int64_t* launches_out);
 int pih_set_timing(pih_handle* h, int enable);

@@ -139,6 +139,23 @@ def ik(q0, tpos, tquat, cfg=None):
     lib().piho_ik(C.byref(cfg), _dp(q0), _dp(tp), _dp(tq), _dp(out)); return out
 
 
+def fk_ur5(q, link=6):
+    q = np.ascontiguousarray(q, dtype=np.float64); p = np.zeros(3); qt = np.zeros(4)
+    lib().piho_fk_ur5(_dp(q), C.c_int(link), _dp(p), _dp(qt)); return p, qt
+
+
+def jacobian_ur5(q):
+    q = np.ascontiguousarray(q, dtype=np.float64); Jl = np.zeros((3, 6)); Ja = np.zeros((3, 6))
+    lib().piho_jacobian_ur5(_dp(q), _dp(Jl), _dp(Ja)); return Jl, Ja
+
+
+def ik_ur5(q0, tpos, tquat, cfg=None):
+    cfg = cfg or default_config()
+    q0 = np.ascontiguousarray(q0, dtype=np.float64); tp = np.ascontiguousarray(tpos, dtype=np.float64)
+    tq = np.ascontiguousarray(tquat, dtype=np.float64); out = np.zeros(6)
+    lib().piho_ik_ur5(C.byref(cfg), _dp(q0), _dp(tp), _dp(tq), _dp(out)); return out
+
+
 def mass_matrix(state):
     s = np.ascontiguousarray(state, dtype=np.float64); M = np.zeros((NDOF, NDOF)); lib().piho_mass_matrix(_dp(s), _dp(M)); return M
 

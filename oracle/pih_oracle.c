@@ -380,6 +380,68 @@ static void ik_solve(const piho_config* c, const double* q0, const v3 tpos, cons
   memcpy(qout, q, sizeof q);
 }
 
+/* ------------------------------------------------------------------------------------------ UR5 chain (p2/p3 for ur_execute, envs/utils.py:70-82) */
+static const double UR5_RFIX[6][9] = PIH_UR5_RFIX;
+static const double UR5_TFIX[6][3] = PIH_UR5_TFIX;
+static const double UR5_AXIS[6][3] = PIH_UR5_AXIS;
+static const double UR5_BASE_T[3] = PIH_UR5_BASE_T;
+static const double UR5_EE_R[9] = PIH_UR5_EE_R;
+static const double UR5_EE_T[3] = PIH_UR5_EE_T;
+/* world pose of every joint frame (revolute chain) + end-effector frame */
+static void ur5_fk(const double* q, double R[6][9], v3 o[6], v3 a[6], v3 ep, double* eR) {
+  double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; v3 op; v_cp(op, UR5_BASE_T);
+  for (int i = 0; i < 6; i++) {
+    double Rj[9], Rq[9]; v3 t;
+    m_mul(Rj, Rp, UR5_RFIX[i]); m_mulv(t, Rp, UR5_TFIX[i]); v_add(o[i], op, t);
+    m_axis_angle(Rq, UR5_AXIS[i], q[i]); m_mul(R[i], Rj, Rq);
+    m_mulv(a[i], Rj, UR5_AXIS[i]);
+    memcpy(Rp, R[i], sizeof Rp); v_cp(op, o[i]);
+  }
+  v3 t; m_mulv(t, Rp, UR5_EE_T); v_add(ep, op, t); m_mul(eR, Rp, UR5_EE_R);
+}
+void piho_fk_ur5(const double q[6], int link /* 0..5 or 6 = ee_link */, double pos[3], double quat[4]) {
+  double R[6][9], eR[9]; v3 o[6], a[6], ep;
+  ur5_fk(q, R, o, a, ep, eR);
+  if (link >= 6) { v_cp(pos, ep); m_to_q(quat, eR); } else { v_cp(pos, o[link]); m_to_q(quat, R[link]); }
+}
+void piho_jacobian_ur5(const double q[6], double Jlin[18], double Jang[18]) {
+  double R[6][9], eR[9]; v3 o[6], a[6], ep;
+  ur5_fk(q, R, o, a, ep, eR);
+  for (int j = 0; j < 6; j++) { v3 r, t; v_sub(r, ep, o[j]); v_cross(t, a[j], r); for (int k = 0; k < 3; k++) { Jlin[k * 6 + j] = t[k]; Jang[k * 6 + j] = a[j][k]; } }
+}
+/* same restated BussIK DLS as ik_solve, over the 6 UR5 joints */
+void piho_ik_ur5(const piho_config* c, const double q0[6], const double tpos[3], const double tquat[4], double qout[6]) {
+  double q[6]; memcpy(q, q0, sizeof q);
+  const double maxstep = 30.0 * PI / 180.0;
+  for (int it = 0; it < c->ik_iters; it++) {
+    double R[6][9], eR[9], cq[4]; v3 o[6], a[6], p;
+    ur5_fk(q, R, o, a, p, eR); m_to_q(cq, eR);
+    double e[6]; v_sub(e, tpos, p);
+    if (v_norm(e) < c->ik_residual) break;
+    double ci[4] = {-cq[0], -cq[1], -cq[2], cq[3]}, dq[4];
+    q_mul(dq, tquat, ci);
+    double w = clampd(dq[3], -1.0, 1.0), ang = 2.0 * acos(w), s2 = 1.0 - w * w;
+    v3 ax;
+    if (s2 < 1e-14) v_set(ax, 1, 0, 0); else { double sc = 1.0 / sqrt(s2); v_set(ax, dq[0] * sc, dq[1] * sc, dq[2] * sc); }
+    if (ang > PI) ang -= 2 * PI;
+    double an = v_norm(ax); if (an > 0) { ax[0] /= an; ax[1] /= an; ax[2] /= an; }
+    e[3] = ang * ax[0]; e[4] = ang * ax[1]; e[5] = ang * ax[2];
+    double J[36];
+    for (int j = 0; j < 6; j++) { v3 r, t; v_sub(r, p, o[j]); v_cross(t, a[j], r); for (int k = 0; k < 3; k++) { J[k * 6 + j] = t[k]; J[(3 + k) * 6 + j] = a[j][k]; } }
+    double A[36], b[6];
+    for (int i = 0; i < 6; i++) {
+      double sb = 0; for (int r = 0; r < 6; r++) sb += J[r * 6 + i] * e[r];
+      b[i] = sb;
+      for (int j = 0; j < 6; j++) { double t = 0; for (int r = 0; r < 6; r++) t += J[r * 6 + i] * J[r * 6 + j]; A[i * 6 + j] = t + (i == j ? c->ik_damping : 0.0); }
+    }
+    cholesky(A, 6, 6); chol_solve(A, 6, 6, b);
+    double mx = 0; for (int i = 0; i < 6; i++) if (fabs(b[i]) > mx) mx = fabs(b[i]);
+    double sc = mx > maxstep ? maxstep / mx : 1.0;
+    for (int i = 0; i < 6; i++) q[i] += sc * b[i];
+  }
+  memcpy(qout, q, sizeof q);
+}
+
 /* ------------------------------------------------------------------------------------------ handle */
 typedef struct { int linkA, linkB, key; v3 p, n; double depth, mu; } Contact;
 typedef struct {

@@ -71,6 +71,10 @@ void piho_get_ncontacts(const piho_handle* h, int32_t* out /* [n] */);
 void piho_fk_arm(const double q[9], int link /* 0..8, or 9 = EE */, double pos[3], double quat[4]);
 void piho_jacobian_ee(const double q[9], double Jlin[27], double Jang[27]);     /* row-major 3x9 each */
 void piho_ik(const piho_config* c, const double q0[9], const double tpos[3], const double tquat[4], double qout[9]);
+/* UR5 chain (envs/assets/urdf/ur5.urdf): getLinkState / Jacobian / calculateInverseKinematics for ur_execute (envs/utils.py:70-82) */
+void piho_fk_ur5(const double q[6], int link /* 0..5, or 6 = ee_link */, double pos[3], double quat[4]);
+void piho_jacobian_ur5(const double q[6], double Jlin[18], double Jang[18]);
+void piho_ik_ur5(const piho_config* c, const double q0[6], const double tpos[3], const double tquat[4], double qout[6]);
 void piho_mass_matrix(const double state[128], double M[38 * 38]);
 void piho_free_accel(const piho_config* c, const double state[128], double udot[38]);
 void piho_vel_constraint(const double cur[3], const double tar[3], double dv, double out[3]);

@@ -60,6 +60,14 @@ PIH_CONST int SAMP_LINK[NSAMP] = PIH_PIPE_SAMP_LINK;
 PIH_CONST real SAMP_Y[NSAMP] = PIH_PIPE_SAMP_Y;
 PIH_CONST int SAMP_VERTEX[NSAMP] = PIH_PIPE_SAMP_VERTEX;
 PIH_CONST real HOLE_POS[3] = PIH_HOLE_POS;
+PIH_CONST real UR5_RFIX[6][9] = PIH_UR5_RFIX;
+PIH_CONST real UR5_TFIX[6][3] = PIH_UR5_TFIX;
+PIH_CONST real UR5_AXIS[6][3] = PIH_UR5_AXIS;
+PIH_CONST real UR5_BASE_T[3] = PIH_UR5_BASE_T;
+PIH_CONST real UR5_EE_R[9] = PIH_UR5_EE_R;
+PIH_CONST real UR5_EE_T[3] = PIH_UR5_EE_T;
+PIH_CONST real IDENT3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+PIH_CONST real ZERO3[3] = {0, 0, 0};
 // envs/peg_in_hole.py:206-212,263: the reference's clock `t += 1/240; if t > dur[s]` evaluated in fp64 fires after exactly
 // FSM_STEPS[s] calls; the device counts steps (fp32 accumulation of 1/240 would fire one step late in some states)
 PIH_CONST int FSM_STEPS[10] = PIH_FSM_STEPS;
@@ -238,29 +246,53 @@ PIH_HD void tip_pose(const Shared& sh, real* out) {
 }
 
 // ------------------------------------------------------------------------------------------------ IK (p2)
+// Serial revolute chains the IK runs on: the 7 Panda arm joints (envs/utils.py:67) and the 6 UR5 joints (envs/utils.py:79)
+struct PandaChain {
+  static constexpr int N = 7;
+  PIH_HD static const real* rfix(int L) { return L_RFIX[L]; }
+  PIH_HD static const real* tfix(int L) { return L_TFIX[L]; }
+  PIH_HD static const real* axis(int L) { return L_AXIS[L]; }
+  PIH_HD static const real* base_r() { return ARM_BASE_R; }
+  PIH_HD static const real* base_t() { return ZERO3; }
+  PIH_HD static const real* ee_r() { return EE_R; }
+  PIH_HD static const real* ee_t() { return EE_T; }
+};
+struct Ur5Chain {
+  static constexpr int N = 6;
+  PIH_HD static const real* rfix(int L) { return UR5_RFIX[L]; }
+  PIH_HD static const real* tfix(int L) { return UR5_TFIX[L]; }
+  PIH_HD static const real* axis(int L) { return UR5_AXIS[L]; }
+  PIH_HD static const real* base_r() { return IDENT3; }
+  PIH_HD static const real* base_t() { return UR5_BASE_T; }
+  PIH_HD static const real* ee_r() { return UR5_EE_R; }
+  PIH_HD static const real* ee_t() { return UR5_EE_T; }
+};
 // BussIK DLS as driven by pybullet.calculateInverseKinematics without null-space arguments [UNVERIFIED restatement]:
-// dq = (J^T J + d I)^-1 J^T e over all 9 movable DOF (finger columns are zero => 7x7), |dq|_inf <= 30 deg.
-template <class W> PIH_HD void ik_solve(W& w, Shared& sh, const Params& P, const real* q0, V3 tpos, Q4 tq, real* qout) {
-  real q[7];
+// dq = (J^T J + d I)^-1 J^T e over the movable DOF (Panda finger columns are zero => 7x7; UR5 6x6), |dq|_inf <= 30 deg.
+// ik_T: LDS scratch [N][12] for the lane-parallel local transforms.
+template <class C, class W> PIH_HD void ik_chain(W& w, real (*ik_T)[12], const Params& P, const real* q0, V3 tpos, Q4 tq, real* qout) {
+  constexpr int N = C::N;
+  real q[N];
 #pragma unroll
-  for (int i = 0; i < 7; i++) q[i] = q0[i];
+  for (int i = 0; i < N; i++) q[i] = q0[i];
   const real maxstep = (real)(30.0 * 3.14159265358979323846 / 180.0);
   for (int it = 0; it < P.ikiters; it++) {
-    w.par(7, [&](int L) {
+    w.par(N, [&](int L) {
       real qq = q[0];
 #pragma unroll
-      for (int k = 1; k < 7; k++) qq = (L == k) ? q[k] : qq;
-      local_transform(L, qq, sh.S, sh.ik_T[L]);
+      for (int k = 1; k < N; k++) qq = (L == k) ? q[k] : qq;
+      M3 R = mul(ldm(C::rfix(L)), axis_angle(ld3(C::axis(L)), qq));
+      stm(ik_T[L], R); st3(ik_T[L] + 9, ld3(C::tfix(L)));
     });
-    V3 a[7], o[7];
-    M3 R = ldm(ARM_BASE_R); V3 org = mk(0, 0, 0);
+    V3 a[N], o[N];
+    M3 R = ldm(C::base_r()); V3 org = ld3(C::base_t());
 #pragma unroll
-    for (int L = 0; L < 7; L++) {
-      M3 Tl = ldm(sh.ik_T[L]); V3 tl = ld3(sh.ik_T[L] + 9);
+    for (int L = 0; L < N; L++) {
+      M3 Tl = ldm(ik_T[L]); V3 tl = ld3(ik_T[L] + 9);
       org = org + mul(R, tl); R = mul(R, Tl);
-      o[L] = org; a[L] = col(R, 2);    // every arm joint axis is local z
+      o[L] = org; a[L] = mul(R, ld3(C::axis(L)));     // a revolute axis is invariant under its own rotation
     }
-    M3 Re = mul(R, ldm(EE_R)); V3 p = org + mul(R, ld3(EE_T));
+    M3 Re = mul(R, ldm(C::ee_r())); V3 p = org + mul(R, ld3(C::ee_t()));
     Q4 cq = m_to_q(Re);
     V3 ep = tpos - p;
     if (norm(ep) < P.ikres) break;
@@ -273,23 +305,23 @@ template <class W> PIH_HD void ik_solve(W& w, Shared& sh, const Params& P, const
     V3 ax = sn < (real)1e-12 ? mk(1, 0, 0) : ((real)1 / sn) * dv3;
     if (ang > PIH_PI) ang -= 2 * PIH_PI;
     V3 er = ang * ax;
-    V3 jl[7];
-    real b[7], A[7][7];
+    V3 jl[N];
+    real b[N], A[N][N];
 #pragma unroll
-    for (int j = 0; j < 7; j++) { jl[j] = cross(a[j], p - o[j]); b[j] = dot(jl[j], ep) + dot(a[j], er); }
+    for (int j = 0; j < N; j++) { jl[j] = cross(a[j], p - o[j]); b[j] = dot(jl[j], ep) + dot(a[j], er); }
 #pragma unroll
-    for (int i = 0; i < 7; i++)
+    for (int i = 0; i < N; i++)
 #pragma unroll
       for (int j = 0; j <= i; j++) A[i][j] = dot(jl[i], jl[j]) + dot(a[i], a[j]) + (i == j ? P.ikdamp : (real)0);
     // Cholesky (lower) + solve, fully unrolled
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
+    for (int j = 0; j < N; j++) {
       real s = A[j][j];
 #pragma unroll
       for (int k = 0; k < j; k++) s -= A[j][k] * A[j][k];
       real d = (real)sqrt(s); A[j][j] = d; real di = (real)1 / d;
 #pragma unroll
-      for (int i = j + 1; i < 7; i++) {
+      for (int i = j + 1; i < N; i++) {
         real t = A[i][j];
 #pragma unroll
         for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k];
@@ -297,24 +329,27 @@ template <class W> PIH_HD void ik_solve(W& w, Shared& sh, const Params& P, const
       }
     }
 #pragma unroll
-    for (int i = 0; i < 7; i++) { real s = b[i];
+    for (int i = 0; i < N; i++) { real s = b[i];
 #pragma unroll
       for (int k = 0; k < i; k++) s -= A[i][k] * b[k];
       b[i] = s / A[i][i]; }
 #pragma unroll
-    for (int i = 6; i >= 0; i--) { real s = b[i];
+    for (int i = N - 1; i >= 0; i--) { real s = b[i];
 #pragma unroll
-      for (int k = i + 1; k < 7; k++) s -= A[k][i] * b[k];
+      for (int k = i + 1; k < N; k++) s -= A[k][i] * b[k];
       b[i] = s / A[i][i]; }
     real mx = 0;
 #pragma unroll
-    for (int i = 0; i < 7; i++) mx = absr(b[i]) > mx ? absr(b[i]) : mx;
+    for (int i = 0; i < N; i++) mx = absr(b[i]) > mx ? absr(b[i]) : mx;
     real sc = mx > maxstep ? maxstep / mx : (real)1;
 #pragma unroll
-    for (int i = 0; i < 7; i++) q[i] += sc * b[i];
+    for (int i = 0; i < N; i++) q[i] += sc * b[i];
   }
 #pragma unroll
-  for (int i = 0; i < 7; i++) qout[i] = q[i];
+  for (int i = 0; i < N; i++) qout[i] = q[i];
+}
+template <class W> PIH_HD void ik_solve(W& w, Shared& sh, const Params& P, const real* q0, V3 tpos, Q4 tq, real* qout) {
+  ik_chain<PandaChain>(w, sh.ik_T, P, q0, tpos, tq, qout);
 }
 
 // ------------------------------------------------------------------------------------------------ reset

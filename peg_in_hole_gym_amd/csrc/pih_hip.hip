@@ -79,6 +79,24 @@ __global__ void __launch_bounds__(64) pih_ik_kernel(Params P, const float* __res
   }
 }
 
+// stand-alone UR5 IK (envs/utils.py:79): q0 float[n,6] -> qout float[n,6]
+__global__ void __launch_bounds__(64) pih_ik_ur5_kernel(Params P, const float* __restrict__ q0, const float* __restrict__ tpos,
+                                                        const float* __restrict__ tquat, float* __restrict__ qout) {
+  __shared__ float ikT[7][12];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  Wave w; w.l = lane; w.counter = 0;
+  float q[6];
+  for (int k = 0; k < 6; k++) q[k] = q0[i * 6 + k];
+  Q4 tq; tq.x = tquat[4 * i]; tq.y = tquat[4 * i + 1]; tq.z = tquat[4 * i + 2]; tq.w = tquat[4 * i + 3];
+  float qs[6];
+  ik_chain<Ur5Chain>(w, ikT, P, q, mk(tpos[3 * i], tpos[3 * i + 1], tpos[3 * i + 2]), tq, qs);
+  if (lane < 6) {
+    float v = 0;
+    for (int k = 0; k < 6; k++) v += qs[k] * (lane == k);
+    qout[i * 6 + lane] = v;
+  }
+}
+
 __global__ void pih_gather_kernel(const float* __restrict__ state, float* __restrict__ out, int n, int word0, int nwords) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * nwords) return;
@@ -233,6 +251,13 @@ int pih_set_state(pih_handle* h, int field, const void* in_dev, void* stream) {
 int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream) {
   if (!h || n <= 0 || !q0_dev || !tpos_dev || !tquat_dev || !qout_dev) return -2;
   hipLaunchKernelGGL(pih_ik_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, h->P, q0_dev, tpos_dev, tquat_dev, qout_dev);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int pih_ik_ur5(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream) {
+  if (!h || n <= 0 || !q0_dev || !tpos_dev || !tquat_dev || !qout_dev) return -2;
+  hipLaunchKernelGGL(pih_ik_ur5_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, h->P, q0_dev, tpos_dev, tquat_dev, qout_dev);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -63,6 +63,19 @@ def random_pos_in_panda_space():
     return np.array([x, y, z])
 
 
+def ur_execute(backend, q, action, position_gain=0.03, max_force=300.0):
+    """Host mirror of ur_execute (envs/utils.py:70-82) for a batch: pos = action[:, :3], orn = quat(euler(action[:, 3:6])),
+    jointPoses = calculateInverseKinematics(ur, ee, pos, orn) on the GPU (pih_ik_ur5).  Returns (jointPoses [n,6],
+    positionGains, forces) -- what the reference hands to setJointMotorControlArray.  (The UR5 dynamics are not part of
+    this build; the task that uses this controller does not exist in the reference snapshot.)"""
+    import torch
+    a = torch.as_tensor(action, dtype=torch.float32)
+    r, p, y = a[:, 3] * 0.5, a[:, 4] * 0.5, a[:, 5] * 0.5
+    cr, sr, cp, sp, cy, sy = r.cos(), r.sin(), p.cos(), p.sin(), y.cos(), y.sin()
+    quat = torch.stack([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy], 1)
+    return backend.ik_ur5(torch.as_tensor(q, dtype=torch.float32), a[:, :3], quat), [position_gain] * 6, [max_force] * 6
+
+
 def env_offsets(offset, n):
     """BaseEnv._create_env placement (envs/base_env.py:35-55): a line when offset.x or offset.y is 0, else a
     ceil(sqrt(n)) grid.  Returns float array [n,3]."""

@@ -117,6 +117,17 @@ class PihVecEnv:
             self._chk(self.L.pih_ik(self.h, n, q0.data_ptr(), tpos.data_ptr(), tquat.data_ptr(), out.data_ptr(), self._stream()), "pih_ik")
         return out
 
+    def ik_ur5(self, q0, tpos, tquat):
+        """Batched calculateInverseKinematics for the UR5 chain (ur_execute, envs/utils.py:79): q0 [n,6] -> q* [n,6]."""
+        q0 = q0.to(device=self.device, dtype=torch.float32).contiguous()
+        tpos = tpos.to(device=self.device, dtype=torch.float32).contiguous()
+        tquat = tquat.to(device=self.device, dtype=torch.float32).contiguous()
+        n = q0.shape[0]
+        out = torch.empty(n, 6, device=self.device)
+        with torch.cuda.device(self.device):
+            self._chk(self.L.pih_ik_ur5(self.h, n, q0.data_ptr(), tpos.data_ptr(), tquat.data_ptr(), out.data_ptr(), self._stream()), "pih_ik_ur5")
+        return out
+
     def set_timing(self, enable):
         self.L.pih_set_timing(self.h, int(enable))
 

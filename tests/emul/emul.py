@@ -54,6 +54,7 @@ def lib(prec):
         L.emul_get_debug.argtypes = [C.c_void_p, dp]
         L.emul_set_dv.argtypes = [C.c_void_p, C.c_double]
         L.emul_ik.argtypes = [C.POINTER(PihConfig), dp, dp, dp, dp]
+        L.emul_ik_ur5.argtypes = [C.POINTER(PihConfig), dp, dp, dp, dp]
         _libs[prec] = L
     return _libs[prec]
 
@@ -101,3 +102,10 @@ def ik(q0, tpos, tquat, prec="f64", cfg=None):
     q0 = np.ascontiguousarray(q0, dtype=np.float64); tp = np.ascontiguousarray(tpos, dtype=np.float64)
     tq = np.ascontiguousarray(tquat, dtype=np.float64); out = np.zeros(9)
     lib(prec).emul_ik(C.byref(cfg), _dp(q0), _dp(tp), _dp(tq), _dp(out)); return out
+
+
+def ik_ur5(q0, tpos, tquat, prec="f64", cfg=None):
+    cfg = cfg or default_config()
+    q0 = np.ascontiguousarray(q0, dtype=np.float64); tp = np.ascontiguousarray(tpos, dtype=np.float64)
+    tq = np.ascontiguousarray(tquat, dtype=np.float64); out = np.zeros(6)
+    lib(prec).emul_ik_ur5(C.byref(cfg), _dp(q0), _dp(tp), _dp(tq), _dp(out)); return out

@@ -75,4 +75,11 @@ void emul_ik(const pih_config* c, const double* q0, const double* tpos, const do
   ik_solve(w, sh, P, q, mk((real)tpos[0], (real)tpos[1], (real)tpos[2]), tq, qo);
   for (int i = 0; i < 7; i++) qout[i] = qo[i]; qout[7] = q0[7]; qout[8] = q0[8];
 }
+void emul_ik_ur5(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout) {
+  static real ikT[7][12]; Params P = make_params(c); Wave w;
+  real q[6], qo[6]; for (int i = 0; i < 6; i++) q[i] = (real)q0[i];
+  Q4 tq; tq.x = (real)tquat[0]; tq.y = (real)tquat[1]; tq.z = (real)tquat[2]; tq.w = (real)tquat[3];
+  ik_chain<Ur5Chain>(w, ikT, P, q, mk((real)tpos[0], (real)tpos[1], (real)tpos[2]), tq, qo);
+  for (int i = 0; i < 6; i++) qout[i] = qo[i];
+}
 }

@@ -208,4 +208,23 @@ for dur in durs:
             break
     fsm_steps.append(k)
 print("#define PIH_FSM_STEPS " + iarr(fsm_steps) + "  /* update_state() calls per FSM state (exact replay of the fp64 clock) */")
+# ----------------------------------------------------------------------------- UR5 (envs/assets/urdf/ur5.urdf, exact)
+ur = [  # (rpy, xyz, axis)  shoulder_pan :32-38, shoulder_lift :60-66, elbow :88-94, wrist_1 :116-122, wrist_2 :145-151, wrist_3 :173-179
+    ((0.0, 0.0, 3.14), (0.0, 0.0, 0.089159), (0, 0, 1)),
+    ((0.0, 1.6, 0.0), (0.0, 0.13585, 0.0), (0, 1, 0)),
+    ((0.0, 0.0, 0.0), (0.0, -0.1197, 0.425), (0, 1, 0)),
+    ((0.0, 1.57079632679, 0.0), (0.0, 0.0, 0.39225), (0, 1, 0)),
+    ((0.0, 0.0, 0.0), (0.0, 0.093, 0.0), (0, 0, 1)),
+    ((0.0, 0.0, 0.0), (0.0, 0.0, 0.09465), (0, 1, 0)),
+]
+print("/* UR5 kinematic chain (ur5.urdf:32-218; world->base fixed xyz 0 0 0.1 :534-539; ee_fixed_joint :201-205), literal 3.14 / 1.6 */")
+print("#define PIH_UR5_NJ 6")
+print("#define PIH_UR5_RFIX {" + ", ".join(arr(rpy(*j[0]).reshape(-1)) for j in ur) + "}")
+print("#define PIH_UR5_TFIX {" + ", ".join(arr(j[1]) for j in ur) + "}")
+print("#define PIH_UR5_AXIS {" + ", ".join(arr(j[2]) for j in ur) + "}")
+print("#define PIH_UR5_BASE_T {0.0, 0.0, 0.1}")
+print("#define PIH_UR5_EE_R " + arr(rpy(0.0, 0.0, 1.57079632679).reshape(-1)))
+print("#define PIH_UR5_EE_T {0.0, 0.0823, 0.0}")
+print("#define PIH_UR5_EFFORT {300.0, 300.0, 300.0, 300.0, 300.0, 300.0}   /* getJointInfo(i)[10], envs/utils.py:75-78 */")
+print("#define PIH_UR5_KP 0.03   /* positionGains, envs/utils.py:82 */")
 print("#endif")
