@@ -21,7 +21,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-o", OUT, SRC]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffast-math", "-o", OUT, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

@@ -109,7 +109,7 @@ PIH_HD int link_dof(int L) { return L < ANL ? L : (L == ANL ? 9 : L + 5); }
 struct ArenaA {
   real Tl[NL][12];                 // local (parent->link) transforms
   real LR[NL][9], LRC[NL][3], LIC[NL][6];   // world rotation, com offset, inertia about com (world axes)
-  areal IA[NL][21], PA[NL][6];     // articulated inertia (A6 B9 C6) / bias force accumulators
+  alignas(16) areal IAP[NL][28];   // per link: own spatial inertia about the link origin (A6 B9 C6) + bias force (6) + pad
   real CB[NL][6];                  // velocity-product accelerations, then (alpha, acc) of each link
   real SP[NSAMP][3];               // collision sample spheres
 };
@@ -157,6 +157,7 @@ PIH_HD real* wma_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + WMA_OFF + j * 
 // ------------------------------------------------------------------------------------------------ wave context
 #ifdef PIH_HOST_EMUL
 struct Wave {
+  void stamp(int) {}
   int lane() const { return 0; }
   void sync() {}
   template <class F> void par(int n, F f) { for (int i = 0; i < n; i++) f(i); }
@@ -171,6 +172,8 @@ struct Wave {
 struct Wave {
   int l;
   int counter;
+  real* dbg = nullptr; int dbgmode = 0; long long t0 = 0;   // diagnostic sub-phase stamps (config.debug == 2)
+  PIH_HD void stamp(int k) { if (dbg && dbgmode == 2) { long long t = __builtin_readcyclecounter(); if (l == 0) dbg[900 + k] = (real)(t - t0); t0 = t; } }
   PIH_HD int lane() const { return l; }
   PIH_HD void sync() { __syncthreads(); }
   template <class F> PIH_HD void par(int n, F f) {
@@ -595,7 +598,9 @@ PIH_HD void link_velocities(Shared& sh) {
 // Articulated-body algorithm; leaves U, 1/D, r per link and the inverse root inertia for the impulse responses,
 // and the free acceleration in sh.udot.
 template <class W> PIH_HD void aba(W& w, Shared& sh) {
+  w.stamp(15);
   link_velocities(sh);
+  w.stamp(8);
   // per-link spatial inertia about the link origin, velocity-product acceleration and bias force (lane = link)
   w.par(NL, [&](int L) {
     int p = L_PARENT[L], jt = L_JTYPE[L];
@@ -603,7 +608,7 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
     V3 rc = ld3(sh.a.LRC[L]); S3 Ic = lds3(sh.a.LIC[L]);
     V3 wv = ld3(sh.VW[L]), vv = ld3(sh.VV[L]);
     // A = Ic + m (|rc|^2 1 - rc rc^T), B = m [rc]x, C = m 1
-    areal* I = sh.a.IA[L];
+    areal* I = sh.a.IAP[L];
     real r2 = dot(rc, rc);
     I[0] = Ic.xx + m * (r2 - rc.x * rc.x); I[1] = Ic.yy + m * (r2 - rc.y * rc.y); I[2] = Ic.zz + m * (r2 - rc.z * rc.z);
     I[3] = Ic.xy - m * rc.x * rc.y; I[4] = Ic.xz - m * rc.x * rc.z; I[5] = Ic.yz - m * rc.y * rc.z;
@@ -625,16 +630,29 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
     real sv = PIH_LIN_DAMP + PIH_LIN_DAMP * norm(vc), sw = PIH_ANG_DAMP + PIH_ANG_DAMP * norm(wv);
     V3 f = m * cross(wv, wrc) - mk(0, 0, m * (real)PIH_GRAVITY_Z) + (m * sv) * vc;
     V3 n = cross(wv, Iw) + sw * Iw + cross(rc, f);
-    sh.a.PA[L][0] = n.x; sh.a.PA[L][1] = n.y; sh.a.PA[L][2] = n.z; sh.a.PA[L][3] = f.x; sh.a.PA[L][4] = f.y; sh.a.PA[L][5] = f.z;
+    I[21] = n.x; I[22] = n.y; I[23] = n.z; I[24] = f.x; I[25] = f.y; I[26] = f.z; I[27] = 0;
   });
-  // inward sweep (wave-uniform)
+  w.stamp(9);
+  // inward sweep (wave-uniform).  The running articulated inertia / bias force of the chain is carried in registers
+  // (`carry` = contribution of the already-visited child, translated to this link's origin); only the link's own
+  // inertia is read from LDS (7 x b128).  The arm's two fingers (links 7, 8) both feed link 6: finger 8 is parked in `hold`.
+  areal carry[27], hold[27], rootp[6];
+  for (int i = 0; i < 27; i++) { carry[i] = 0; hold[i] = 0; }
   for (int L = NL - 1; L >= 0; L--) {
     int p = L_PARENT[L], jt = L_JTYPE[L];
-    const areal* I = sh.a.IA[L];
+    const bool leaf = (L == NL - 1) || (L == ANL - 1) || (L == ANL - 2);
+    areal own[28];
+#pragma unroll
+    for (int i = 0; i < 7; i++) { real4 v = reinterpret_cast<const real4*>(sh.a.IAP[L])[i]; own[4 * i] = v.x; own[4 * i + 1] = v.y; own[4 * i + 2] = v.z; own[4 * i + 3] = v.w; }
+    if (!leaf) {
+#pragma unroll
+      for (int i = 0; i < 27; i++) own[i] += carry[i];
+    }
+    const areal* I = own;
     areal A[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]};
     areal B[9]; for (int i = 0; i < 9; i++) B[i] = I[6 + i];
     areal C[9] = {I[15], I[18], I[19], I[18], I[16], I[20], I[19], I[20], I[17]};
-    areal pa[3] = {sh.a.PA[L][0], sh.a.PA[L][1], sh.a.PA[L][2]}, pl[3] = {sh.a.PA[L][3], sh.a.PA[L][4], sh.a.PA[L][5]};
+    areal pa[3] = {I[21], I[22], I[23]}, pl[3] = {I[24], I[25], I[26]};
     if (jt == PIH_JT_FLOATING) {
       // root: invert the 6x6 articulated inertia [[A,B],[B^T,C]] (order: angular, linear) by Gauss-Jordan (SPD)
       areal Mx[6][6], Iv[6][6];
@@ -653,6 +671,7 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
         }
       }
       for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.Inv6[6 * i + j] = (real)Iv[i][j];
+      for (int i = 0; i < 3; i++) { rootp[i] = pa[i]; rootp[3 + i] = pl[i]; }
       continue;
     }
     const areal a[3] = {sh.LA[L][0], sh.LA[L][1], sh.LA[L][2]};
@@ -691,23 +710,26 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
       areal mx = Bn[3 * i], my = Bn[3 * i + 1], mz = Bn[3 * i + 2];
       Y[3 * i] = my * r[2] - mz * r[1]; Y[3 * i + 1] = mz * r[0] - mx * r[2]; Y[3 * i + 2] = mx * r[1] - my * r[0];
     }
-    areal* Ip = sh.a.IA[p];
-    Ip[0] += A[0] + X[0] - Y[0]; Ip[1] += A[4] + X[4] - Y[4]; Ip[2] += A[8] + X[8] - Y[8];
-    Ip[3] += A[1] + (areal)0.5 * ((X[1] - Y[1]) + (X[3] - Y[3]));
-    Ip[4] += A[2] + (areal)0.5 * ((X[2] - Y[2]) + (X[6] - Y[6]));
-    Ip[5] += A[5] + (areal)0.5 * ((X[5] - Y[5]) + (X[7] - Y[7]));
-    for (int i = 0; i < 9; i++) Ip[6 + i] += Bn[i];
-    Ip[15] += C[0]; Ip[16] += C[4]; Ip[17] += C[8]; Ip[18] += C[1]; Ip[19] += C[2]; Ip[20] += C[5];
-    areal* Pp = sh.a.PA[p];
-    Pp[0] += qa[0] + (r[1] * ql[2] - r[2] * ql[1]); Pp[1] += qa[1] + (r[2] * ql[0] - r[0] * ql[2]); Pp[2] += qa[2] + (r[0] * ql[1] - r[1] * ql[0]);
-    Pp[3] += ql[0]; Pp[4] += ql[1]; Pp[5] += ql[2];
+    areal T[27];
+    T[0] = A[0] + X[0] - Y[0]; T[1] = A[4] + X[4] - Y[4]; T[2] = A[8] + X[8] - Y[8];
+    T[3] = A[1] + (areal)0.5 * ((X[1] - Y[1]) + (X[3] - Y[3]));
+    T[4] = A[2] + (areal)0.5 * ((X[2] - Y[2]) + (X[6] - Y[6]));
+    T[5] = A[5] + (areal)0.5 * ((X[5] - Y[5]) + (X[7] - Y[7]));
+    for (int i = 0; i < 9; i++) T[6 + i] = Bn[i];
+    T[15] = C[0]; T[16] = C[4]; T[17] = C[8]; T[18] = C[1]; T[19] = C[2]; T[20] = C[5];
+    T[21] = qa[0] + (r[1] * ql[2] - r[2] * ql[1]); T[22] = qa[1] + (r[2] * ql[0] - r[0] * ql[2]); T[23] = qa[2] + (r[0] * ql[1] - r[1] * ql[0]);
+    T[24] = ql[0]; T[25] = ql[1]; T[26] = ql[2];
+    if (L == ANL - 1) { for (int i = 0; i < 27; i++) hold[i] = T[i]; }                    // finger 8: park until finger 7 is done
+    else if (L == ANL - 2) { for (int i = 0; i < 27; i++) carry[i] = T[i] + hold[i]; }    // finger 7: both fingers feed link 6
+    else { for (int i = 0; i < 27; i++) carry[i] = T[i]; }
   }
+  w.stamp(10);
   // outward sweep: accelerations (wave-uniform).  VW/VV are reused to carry (alpha, acc) of each link.
   for (int L = 0; L < NL; L++) {
     int p = L_PARENT[L], jt = L_JTYPE[L], d = link_dof(L);
     V3 al, ac;
     if (jt == PIH_JT_FLOATING) {
-      real pv[6]; for (int i = 0; i < 6; i++) pv[i] = (real)sh.a.PA[L][i];
+      real pv[6]; for (int i = 0; i < 6; i++) pv[i] = (real)rootp[i];
       real x[6];
       for (int i = 0; i < 6; i++) { real s = 0; for (int j = 0; j < 6; j++) s -= sh.Inv6[6 * i + j] * pv[j]; x[i] = s; }
       al = mk(x[0], x[1], x[2]); ac = mk(x[3], x[4], x[5]);
@@ -1249,15 +1271,15 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, const Ovf& ov, int env, 
   for (int i = 0; i < 7; i++) S[PIH_S_TIP + i] = tip[i];
   S[PIH_S_EE] = eep.x + S[PIH_S_OFFSET]; S[PIH_S_EE + 1] = eep.y + S[PIH_S_OFFSET + 1]; S[PIH_S_EE + 2] = eep.z + S[PIH_S_OFFSET + 2];
   bool bad = false;
-  for (int i = 0; i < 86; i++) { real v = S[i]; bad = bad || !(v == v) || absr(v) > (real)1e15; }
+  for (int i = 0; i < 86; i++) bad = bad || !finite_small(S[i]);
   if (!frozen && P.mode == 0 && (rew > 0 || S[PIH_S_STEPS] >= (real)P.maxsteps)) S[PIH_S_DONE] = 1;
   obs[0] = S[PIH_S_QARM + 7]; obs[1] = S[PIH_S_QARM + 8];
   obs[2] = eep.x + S[PIH_S_OFFSET]; obs[3] = eep.y + S[PIH_S_OFFSET + 1]; obs[4] = eep.z + S[PIH_S_OFFSET + 2];
   *reward = rew; *done = (unsigned char)((S[PIH_S_DONE] != 0 || bad) ? 1 : 0);
   w.sync();
   if (bad || (P.autoreset && S[PIH_S_DONE] != 0)) {
-    if (bad) { S[PIH_S_RNG] = (S[PIH_S_RNG] == S[PIH_S_RNG] && S[PIH_S_RNG] >= 0 && S[PIH_S_RNG] < (real)1e7) ? S[PIH_S_RNG] : (real)0;
-               real nb = S[PIH_S_SPARE]; S[PIH_S_SPARE] = (nb == nb && nb >= 0 ? nb : (real)0) + 1; }   // count non-finite resets
+    if (bad) { S[PIH_S_RNG] = (finite_small(S[PIH_S_RNG]) && S[PIH_S_RNG] >= 0 && S[PIH_S_RNG] < (real)1e7) ? S[PIH_S_RNG] : (real)0;
+               real nb = S[PIH_S_SPARE]; S[PIH_S_SPARE] = (finite_small(nb) && nb >= 0 ? nb : (real)0) + 1; }   // count non-finite resets
     reset_state(S, P, P.env0 + env);
     w.sync();
     fk_all(w, sh);

@@ -28,6 +28,7 @@ __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __rest
   if (actions) { a[0] = actions[env * 4]; a[1] = actions[env * 4 + 1]; a[2] = actions[env * 4 + 2]; a[3] = actions[env * 4 + 3]; }
   float o[5], r; unsigned char d;
   Ovf ov; ov.base = ovf + (size_t)env * OVF_WORDS;
+  w.dbg = dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr; w.dbgmode = P.debug;
   step_env(w, sh, P, ov, env, a, o, &r, &d, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
   __syncthreads();
 #pragma unroll

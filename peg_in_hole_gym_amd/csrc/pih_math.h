@@ -39,6 +39,13 @@ PIH_HD real rsqrt_(real x) { return (real)1 / (real)sqrt(x); }
 PIH_HD real norm(V3 a) { return (real)sqrt(dot(a, a)); }
 PIH_HD real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 PIH_HD real absr(real x) { return x < 0 ? -x : x; }
+// |x| < 1e15 and not NaN/Inf, tested on the bit pattern so that it survives -ffast-math (finite-math assumptions)
+#ifdef PIH_HOST_EMUL
+PIH_HD bool finite_small(double x) { return x == x && (x < 0 ? -x : x) <= 1e15; }
+PIH_HD bool finite_small(float x) { return x == x && (x < 0 ? -x : x) <= 1e15f; }
+#else
+PIH_HD bool finite_small(float x) { return (__builtin_bit_cast(unsigned, x) & 0x7fffffffu) <= 0x58635fa9u; }   // 0x58635fa9 = 1e15f
+#endif
 // single-instruction clamp / max on the GPU (v_med3_f32 / v_max_f32); the ?: forms compile to cmp + cndmask pairs
 #ifdef PIH_HOST_EMUL
 PIH_HD real med3_(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }

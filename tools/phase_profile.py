@@ -20,4 +20,6 @@ tot = acc.sum().item()
 for k, nm in enumerate(names):
     print("%-16s %10.0f cycles  %5.1f%%" % (nm, acc[k].item(), 100 * acc[k].item() / tot))
 print("total stamped cycles per env-step: %.0f" % tot)
+sub = env.debug()[:, 908:912].mean(0)
+print("aba sub-phases: link_vel %.0f  init(par) %.0f  inward %.0f  (outward = rest)" % (sub[0].item(), sub[1].item(), sub[2].item()))
 st = env.state(); print("mean contacts %.2f  mean pgs iters %.1f" % (st[:, 106].mean().item(), st[:, 107].mean().item()))
