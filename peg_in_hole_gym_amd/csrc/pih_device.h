@@ -217,15 +217,22 @@ template <class W> PIH_HD void fk_all(W& w, Shared& sh) {
     real q = L < ANL ? sh.S[PIH_S_QARM + L] : (L == ANL ? (real)0 : sh.S[PIH_S_QJ + L - ANL - 1]);
     local_transform(L, q, sh.S, sh.a.Tl[L]);
   });
-  // serial composition down the two chains (wave-uniform)
-  for (int L = 0; L < NL; L++) {
-    int p = L_PARENT[L];
-    M3 Tl = ldm(sh.a.Tl[L]); V3 tl = ld3(sh.a.Tl[L] + 9);
-    M3 R; V3 o;
-    if (L_JTYPE[L] == PIH_JT_FLOATING) { R = Tl; o = tl; }
-    else if (p < 0) { M3 Rp = ldm(ARM_BASE_R); R = mul(Rp, Tl); o = mul(Rp, tl); }
-    else { M3 Rp = ldm(sh.a.LR[p]); R = mul(Rp, Tl); o = ld3(sh.LO[p]) + mul(Rp, tl); }
-    stm(sh.a.LR[L], R); st3(sh.LO[L], o);
+  // serial composition down the two chains (wave-uniform).  The parent's pose is carried in registers (no LDS read-back
+  // on the dependency chain); link 6's pose is kept for the second finger (link 8, whose parent is 6, not 7).
+  {
+    M3 Rp = ldm(ARM_BASE_R), R6 = Rp; V3 op = mk(0, 0, 0), o6 = op;
+    for (int L = 0; L < NL; L++) {
+      M3 Tl = ldm(sh.a.Tl[L]); V3 tl = ld3(sh.a.Tl[L] + 9);
+      M3 R; V3 o;
+      if (L_JTYPE[L] == PIH_JT_FLOATING) { R = Tl; o = tl; }
+      else {
+        if (L == ANL - 1) { Rp = R6; op = o6; }
+        R = mul(Rp, Tl); o = op + mul(Rp, tl);
+      }
+      stm(sh.a.LR[L], R); st3(sh.LO[L], o);
+      Rp = R; op = o;
+      if (L == ANL - 3) { R6 = R; o6 = o; }
+    }
   }
   w.par(NL, [&](int L) {
     M3 R = ldm(sh.a.LR[L]);
@@ -581,17 +588,21 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
 // ------------------------------------------------------------------------------------------------ ABA
 // link velocities from the generalized velocity sh.u (wave-uniform serial sweep)
 PIH_HD void link_velocities(Shared& sh) {
+  V3 wp = mk(0, 0, 0), vp = mk(0, 0, 0), op = mk(0, 0, 0), w6 = wp, v6 = vp, o6 = op;   // parent's twist / origin, in registers
   for (int L = 0; L < NL; L++) {
-    int p = L_PARENT[L], jt = L_JTYPE[L], d = link_dof(L);
-    V3 wv, vv;
+    int jt = L_JTYPE[L], d = link_dof(L);
+    V3 wv, vv, o = ld3(sh.LO[L]);
     if (jt == PIH_JT_FLOATING) { vv = ld3(&sh.u[d]); wv = ld3(&sh.u[d + 3]); }
     else {
-      V3 wp = mk(0, 0, 0), vat = mk(0, 0, 0);
-      if (p >= 0) { wp = ld3(sh.VW[p]); vat = ld3(sh.VV[p]) + cross(wp, ld3(sh.LO[L]) - ld3(sh.LO[p])); }
+      if (L == ANL - 1) { wp = w6; vp = v6; op = o6; }
+      V3 vat = L == 0 ? mk(0, 0, 0) : vp + cross(wp, o - op);
+      if (L == 0) wp = mk(0, 0, 0);
       V3 aq = sh.u[d] * ld3(sh.LA[L]);
       if (jt == PIH_JT_REVOLUTE) { wv = wp + aq; vv = vat; } else { wv = wp; vv = vat + aq; }
     }
     st3(sh.VW[L], wv); st3(sh.VV[L], vv);
+    wp = wv; vp = vv; op = o;
+    if (L == ANL - 3) { w6 = wv; v6 = vv; o6 = o; }
   }
 }
 
@@ -725,29 +736,31 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
   }
   w.stamp(10);
   // outward sweep: accelerations (wave-uniform).  VW/VV are reused to carry (alpha, acc) of each link.
-  for (int L = 0; L < NL; L++) {
-    int p = L_PARENT[L], jt = L_JTYPE[L], d = link_dof(L);
-    V3 al, ac;
-    if (jt == PIH_JT_FLOATING) {
-      real pv[6]; for (int i = 0; i < 6; i++) pv[i] = (real)rootp[i];
-      real x[6];
-      for (int i = 0; i < 6; i++) { real s = 0; for (int j = 0; j < 6; j++) s -= sh.Inv6[6 * i + j] * pv[j]; x[i] = s; }
-      al = mk(x[0], x[1], x[2]); ac = mk(x[3], x[4], x[5]);
-      sh.udot[d] = ac.x; sh.udot[d + 1] = ac.y; sh.udot[d + 2] = ac.z; sh.udot[d + 3] = al.x; sh.udot[d + 4] = al.y; sh.udot[d + 5] = al.z;
-    } else {
-      V3 alp = mk(0, 0, 0), acp = mk(0, 0, 0);
-      if (p >= 0) { alp = ld3(sh.a.CB[p]); acp = ld3(sh.a.CB[p] + 3); }   // parent's (alpha, acc) stored below
-      V3 r = ld3(sh.AR[L]);
-      V3 aa = alp + ld3(sh.a.CB[L]);
-      V3 ll = acp + cross(alp, r) + ld3(sh.a.CB[L] + 3);
-      V3 Ua = ld3(sh.AU[L]), Ul = ld3(sh.AU[L] + 3);
-      real qdd = (sh.Au[L] - dot(Ua, aa) - dot(Ul, ll)) * sh.ADinv[L];
-      V3 a = ld3(sh.LA[L]);
-      if (jt == PIH_JT_REVOLUTE) { al = aa + qdd * a; ac = ll; } else { al = aa; ac = ll + qdd * a; }
-      sh.udot[d] = qdd;
+  {
+    V3 alp = mk(0, 0, 0), acp = mk(0, 0, 0), al6 = alp, ac6 = acp;   // parent's (alpha, acc) in registers
+    for (int L = 0; L < NL; L++) {
+      int jt = L_JTYPE[L], d = link_dof(L);
+      V3 al, ac;
+      if (jt == PIH_JT_FLOATING) {
+        real x[6];
+        for (int i = 0; i < 6; i++) { real sacc = 0; for (int j = 0; j < 6; j++) sacc -= sh.Inv6[6 * i + j] * (real)rootp[j]; x[i] = sacc; }
+        al = mk(x[0], x[1], x[2]); ac = mk(x[3], x[4], x[5]);
+        sh.udot[d] = ac.x; sh.udot[d + 1] = ac.y; sh.udot[d + 2] = ac.z; sh.udot[d + 3] = al.x; sh.udot[d + 4] = al.y; sh.udot[d + 5] = al.z;
+      } else {
+        if (L == 0) { alp = mk(0, 0, 0); acp = mk(0, 0, 0); }
+        if (L == ANL - 1) { alp = al6; acp = ac6; }
+        V3 r = ld3(sh.AR[L]);
+        V3 aa = alp + ld3(sh.a.CB[L]);
+        V3 ll = acp + cross(alp, r) + ld3(sh.a.CB[L] + 3);
+        V3 Ua = ld3(sh.AU[L]), Ul = ld3(sh.AU[L] + 3);
+        real qdd = (sh.Au[L] - dot(Ua, aa) - dot(Ul, ll)) * sh.ADinv[L];
+        V3 a = ld3(sh.LA[L]);
+        if (jt == PIH_JT_REVOLUTE) { al = aa + qdd * a; ac = ll; } else { al = aa; ac = ll + qdd * a; }
+        sh.udot[d] = qdd;
+      }
+      alp = al; acp = ac;
+      if (L == ANL - 3) { al6 = al; ac6 = ac; }
     }
-    // overwrite this link's c with its (alpha, acc): c of a link is never needed again once it has been visited
-    st3(sh.a.CB[L], al); st3(sh.a.CB[L] + 3, ac);
   }
 }
 
@@ -1072,12 +1085,22 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
     // the row constants are re-read from LDS every iteration ON PURPOSE: without this compiler barrier LICM hoists all
     // ~155 loop-invariant loads out of the iteration loop and spills them to scratch inside the hot loop
     __asm__ volatile("" ::: "memory");
+    // row constants come from LDS as 16-byte broadcasts, explicitly prefetched PF records ahead: the dependent chain of one
+    // motor step is ~6 VALU ops (~50 cycles) while an LDS round trip is >100, so a distance-1 prefetch stalls every step
+    constexpr int PF = 4;
+    real4 pm[PF], pa4[PF], pl4[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) { pm[k] = *reinterpret_cast<const real4*>(sh.mrec[9 + k]); pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
 #pragma unroll
     for (int j = 0; j < PIH_OBJ_NJ; j++) {
       real tot_a = 0;
-      if (j < 9) {   // arm joint block: motor, lower limit, upper limit (wave-uniform chain; constants by LDS broadcast)
-        const real di = sh.mrec[j][0], rhs = sh.mrec[j][1], thr = sh.mrec[j][2], lim = sh.mrec[j][3];
-        const real lor = sh.lrec[j][0], hir = sh.lrec[j][1], wjj = sh.lrec[j][2];
+      const real4 cm = pm[j % PF];
+      if (j + PF < PIH_OBJ_NJ) pm[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[9 + j + PF]);
+      if (j < 9) {   // arm joint block: motor, lower limit, upper limit (wave-uniform chain)
+        const real4 ca = pa4[j % PF], cl = pl4[j % PF];
+        if (j + PF < 9) { pa4[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[j + PF]); pl4[j % PF] = *reinterpret_cast<const real4*>(sh.lrec[j + PF]); }
+        const real di = ca.x, rhs = ca.y, thr = ca.z, lim = ca.w;
+        const real lor = cl.x, hir = cl.y, wjj = cl.z;
         real dj = rdlane(du, j);
         real sum = lam_a[j] + (rhs - dj * di);
         sum = med3_(sum, -lim, lim);
@@ -1094,7 +1117,7 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
         tot_a = dl + d2 - d3;
       }
       // pipe joint motor j (DOF 15 + j)
-      const real di = sh.mrec[9 + j][0], rhs = sh.mrec[9 + j][1], thr = sh.mrec[9 + j][2], lim = sh.mrec[9 + j][3];
+      const real di = cm.x, rhs = cm.y, thr = cm.z, lim = cm.w;
       real dj = rdlane(du, 15 + j);
       real sum = lam_p[j] + (rhs - dj * di);
       sum = med3_(sum, -lim, lim);
