@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpih_hip.so")
+LIB_PATH = os.environ.get("PIH_LIB_PATH") or os.path.join(_HERE, "csrc", "libpih_hip.so")   # override: A/B of builds on one box
 
 STATE_WORDS = 256
 DEBUG_WORDS = 1024

@@ -100,7 +100,7 @@ PIH_HD int link_dof(int L) { return L < ANL ? L : (L == ANL ? 9 : L + 5); }
 // Packed per-contact solver record (CREC = 32 words, 128-bit aligned so the PGS loop reads it with b128 broadcasts):
 //  0-2 p | 3 linkA | 4 linkB | 5 mu | 6 arm-row slot | 7 -
 //  8-10 n | 11 dinv_n | 12-14 t1 | 15 dinv_t1 | 16-18 t2 | 19 dinv_t2
-//  20-22 rhs (n,t1,t2) | 23 G[t1][n] | 24 G[t2][n] | 25 G[t2][t1] | 26-28 dvp_n | 29-31 dvp_t1
+//  20-22 rhs (n,t1,t2) | 23 G[t1][n] | 24 G[t2][n] | 25 G[t2][t1] | 26-28 dvp_n, then multipliers | 29-31 dvp_t1, then resid*dinv^2
 // (dvp_k = relative velocity change at the contact point per unit impulse along direction k; G[a][b] = dir_a . dvp_b
 //  are the cross terms that make the in-block (n, t1, t2) update exact Gauss-Seidel)
 
@@ -932,6 +932,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
     V3 t1 = ld3(R + 12), t2 = ld3(R + 16), dn = ld3(R + 26), d1 = ld3(R + 29);
     R[23] = dot(t1, dn); R[24] = dot(t2, dn); R[25] = dot(t2, d1);
     R[26] = sh.r_lam[3 * c]; R[27] = 0; R[28] = 0;   // multipliers (n, t1, t2) live in the record from here on (GPU PGS)
+    R[29] = P.resid * R[11] * R[11]; R[30] = P.resid * R[15] * R[15]; R[31] = P.resid * R[19] * R[19];   // early-exit thresholds resid * dinv^2
   });
 }
 
@@ -968,15 +969,35 @@ PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane mus
 template <int CTRL> PIH_HD real dpp_add(real x) {   // x + x[dpp-permuted lane]  (v_add_f32_dpp)
   return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
-template <int CTRL, int ROWMASK> PIH_HD real dpp_add_rows(real x) {   // rows in ROWMASK: x += dpp-source lane ; others unchanged
+// after row16_sum3: rows 1,3 += lane 15 of the previous row (row_bcast:15), rows 2,3 += lane 31 (row_bcast:31)
+// => lanes 32..47 hold the sum over lanes 0..47 (all 38 DOF lanes).  Written as inline asm because hipcc lowers the
+// masked-row form to v_mov 0 + v_mov_dpp + v_add (3 instructions) instead of one fused v_add_f32_dpp; the s_nop covers the
+// VALU-write -> DPP-read hazard that the compiler does not pad inside asm.
+#ifndef PIH_DPP_ASM
+#define PIH_DPP_ASM 1
+#endif
+#if PIH_DPP_ASM
+PIH_HD void rows012_total3(real& a, real& b, real& c) {
+  __asm__ volatile("s_nop 1\n\t"
+                   "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\t"
+                   "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa\n\t"
+                   "s_nop 1\n\t"
+                   "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc\n\t"
+                   "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc\n\t"
+                   "s_nop 1"
+                   : "+v"(a), "+v"(b), "+v"(c));
+}
+#else
+template <int CTRL, int ROWMASK> PIH_HD real dpp_add_rows(real x) {
   return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, false));
 }
-// after row16_sum3: rows 1,3 += lane 15 of the previous row (row_bcast:15), rows 2,3 += lane 31 (row_bcast:31)
-// => lanes 32..47 hold the sum over lanes 0..47 (all 38 DOF lanes)
 PIH_HD void rows012_total3(real& a, real& b, real& c) {
   a = dpp_add_rows<0x142, 0xA>(a); b = dpp_add_rows<0x142, 0xA>(b); c = dpp_add_rows<0x142, 0xA>(c);
   a = dpp_add_rows<0x143, 0xC>(a); b = dpp_add_rows<0x143, 0xC>(b); c = dpp_add_rows<0x143, 0xC>(c);
 }
+#endif
 // after this every lane holds the sum over its 16-lane row; three independent reductions interleaved for ILP
 PIH_HD void row16_sum3(real& a, real& b, real& c) {
   a = dpp_add<0xB1>(a); b = dpp_add<0xB1>(b); c = dpp_add<0xB1>(c);        // quad_perm [1,0,3,2]
@@ -1160,16 +1181,16 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       real s0 = l0 + (r.q[5].x - jd0 * di0);
       s0 = max_(s0, (real)0);
       real dl0 = s0 - l0;
-      worstc = max_(worstc, dl0 * dl0 - P.resid * di0 * di0);
+      worstc = max_(worstc, dl0 * dl0 - r.q[7].y);
       real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
       if (rdlane(s0, 32) > 0) {               // wave-uniform branch
         real hi = mu * s0;
         jd1 += r.q[5].w * dl0;
         s1 = l1 + (r.q[5].y - jd1 * di1); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
-        worstc = max_(worstc, dl1 * dl1 - P.resid * di1 * di1);
+        worstc = max_(worstc, dl1 * dl1 - r.q[7].z);
         jd2 += r.q[6].x * dl0 + r.q[6].y * dl1;
         s2 = l2 + (r.q[5].z - jd2 * di2); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
-        worstc = max_(worstc, dl2 * dl2 - P.resid * di2 * di2);
+        worstc = max_(worstc, dl2 * dl2 - r.q[7].w);
       }
       if (d == 32) { R[26] = s0; R[27] = s1; R[28] = s2; }
       if (!in_lds) __threadfence_block();     // spilled records live in global memory: make lane 32's store visible to the wave
