@@ -109,7 +109,7 @@ PIH_HD int link_dof(int L) { return L < ANL ? L : (L == ANL ? 9 : L + 5); }
 struct ArenaA {
   real Tl[NL][12];                 // local (parent->link) transforms
   real LR[NL][9], LRC[NL][3], LIC[NL][6];   // world rotation, com offset, inertia about com (world axes)
-  alignas(16) areal IAP[NL][28];   // per link: own spatial inertia about the link origin (A6 B9 C6) + bias force (6) + pad
+  alignas(16) real IAP[NL][28];   // per link: own spatial inertia about the link origin (A6 B9 C6) + bias force (6) + pad
   real CB[NL][6];                  // velocity-product accelerations, then (alpha, acc) of each link
   real SP[NSAMP][3];               // collision sample spheres
 };
@@ -619,7 +619,7 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
     V3 rc = ld3(sh.a.LRC[L]); S3 Ic = lds3(sh.a.LIC[L]);
     V3 wv = ld3(sh.VW[L]), vv = ld3(sh.VV[L]);
     // A = Ic + m (|rc|^2 1 - rc rc^T), B = m [rc]x, C = m 1
-    areal* I = sh.a.IAP[L];
+    real* I = sh.a.IAP[L];
     real r2 = dot(rc, rc);
     I[0] = Ic.xx + m * (r2 - rc.x * rc.x); I[1] = Ic.yy + m * (r2 - rc.y * rc.y); I[2] = Ic.zz + m * (r2 - rc.z * rc.z);
     I[3] = Ic.xy - m * rc.x * rc.y; I[4] = Ic.xz - m * rc.x * rc.z; I[5] = Ic.yz - m * rc.y * rc.z;
@@ -647,27 +647,32 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
   // inward sweep (wave-uniform).  The running articulated inertia / bias force of the chain is carried in registers
   // (`carry` = contribution of the already-visited child, translated to this link's origin); only the link's own
   // inertia is read from LDS (7 x b128).  The arm's two fingers (links 7, 8) both feed link 6: finger 8 is parked in `hold`.
-  areal carry[27], hold[27], rootp[6];
-  for (int i = 0; i < 27; i++) { carry[i] = 0; hold[i] = 0; }
+  // Symmetric storage throughout: A, C as 6 unique entries (xx yy zz xy xz yz), B full 3x3  => ~180 FMAs per link.
+  struct Acc { S3 A; M3 B; S3 C; V3 pa, pl; };
+  auto zero_acc = []() { Acc z; z.A = S3{0, 0, 0, 0, 0, 0}; z.C = z.A; for (int i = 0; i < 9; i++) z.B.m[i] = 0; z.pa = mk(0, 0, 0); z.pl = z.pa; return z; };
+  Acc carry = zero_acc(), hold = zero_acc();
+  areal rootp[6] = {0, 0, 0, 0, 0, 0};
   for (int L = NL - 1; L >= 0; L--) {
     int p = L_PARENT[L], jt = L_JTYPE[L];
     const bool leaf = (L == NL - 1) || (L == ANL - 1) || (L == ANL - 2);
-    areal own[28];
+    real own[28];
 #pragma unroll
     for (int i = 0; i < 7; i++) { real4 v = reinterpret_cast<const real4*>(sh.a.IAP[L])[i]; own[4 * i] = v.x; own[4 * i + 1] = v.y; own[4 * i + 2] = v.z; own[4 * i + 3] = v.w; }
+    S3 A = S3{own[0], own[1], own[2], own[3], own[4], own[5]};
+    M3 B; for (int i = 0; i < 9; i++) B.m[i] = own[6 + i];
+    S3 C = S3{own[15], own[16], own[17], own[18], own[19], own[20]};
+    V3 pa = mk(own[21], own[22], own[23]), pl = mk(own[24], own[25], own[26]);
     if (!leaf) {
-#pragma unroll
-      for (int i = 0; i < 27; i++) own[i] += carry[i];
+      A.xx += carry.A.xx; A.yy += carry.A.yy; A.zz += carry.A.zz; A.xy += carry.A.xy; A.xz += carry.A.xz; A.yz += carry.A.yz;
+      C.xx += carry.C.xx; C.yy += carry.C.yy; C.zz += carry.C.zz; C.xy += carry.C.xy; C.xz += carry.C.xz; C.yz += carry.C.yz;
+      for (int i = 0; i < 9; i++) B.m[i] += carry.B.m[i];
+      pa = pa + carry.pa; pl = pl + carry.pl;
     }
-    const areal* I = own;
-    areal A[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]};
-    areal B[9]; for (int i = 0; i < 9; i++) B[i] = I[6 + i];
-    areal C[9] = {I[15], I[18], I[19], I[18], I[16], I[20], I[19], I[20], I[17]};
-    areal pa[3] = {I[21], I[22], I[23]}, pl[3] = {I[24], I[25], I[26]};
     if (jt == PIH_JT_FLOATING) {
       // root: invert the 6x6 articulated inertia [[A,B],[B^T,C]] (order: angular, linear) by Gauss-Jordan (SPD)
+      M3 Am = s3_to_m(A), Cm = s3_to_m(C);
       areal Mx[6][6], Iv[6][6];
-      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Mx[i][j] = A[3 * i + j]; Mx[i][3 + j] = B[3 * i + j]; Mx[3 + i][j] = B[3 * j + i]; Mx[3 + i][3 + j] = C[3 * i + j]; }
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Mx[i][j] = Am.m[3 * i + j]; Mx[i][3 + j] = B.m[3 * i + j]; Mx[3 + i][j] = B.m[3 * j + i]; Mx[3 + i][3 + j] = Cm.m[3 * i + j]; }
       for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Iv[i][j] = i == j ? (areal)1 : (areal)0;
 #pragma unroll
       for (int k = 0; k < 6; k++) {
@@ -682,57 +687,55 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
         }
       }
       for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.Inv6[6 * i + j] = (real)Iv[i][j];
-      for (int i = 0; i < 3; i++) { rootp[i] = pa[i]; rootp[3 + i] = pl[i]; }
+      rootp[0] = pa.x; rootp[1] = pa.y; rootp[2] = pa.z; rootp[3] = pl.x; rootp[4] = pl.y; rootp[5] = pl.z;
       continue;
     }
-    const areal a[3] = {sh.LA[L][0], sh.LA[L][1], sh.LA[L][2]};
-    areal Ua[3], Ul[3], D, u;
-    areal tau = -(areal)L_DAMPING[L] * (areal)sh.u[link_dof(L)];
-    if (jt == PIH_JT_REVOLUTE) {
-      for (int i = 0; i < 3; i++) { Ua[i] = A[3 * i] * a[0] + A[3 * i + 1] * a[1] + A[3 * i + 2] * a[2]; Ul[i] = B[i] * a[0] + B[3 + i] * a[1] + B[6 + i] * a[2]; }
-      D = a[0] * Ua[0] + a[1] * Ua[1] + a[2] * Ua[2]; u = tau - (a[0] * pa[0] + a[1] * pa[1] + a[2] * pa[2]);
-    } else {
-      for (int i = 0; i < 3; i++) { Ua[i] = B[3 * i] * a[0] + B[3 * i + 1] * a[1] + B[3 * i + 2] * a[2]; Ul[i] = C[3 * i] * a[0] + C[3 * i + 1] * a[1] + C[3 * i + 2] * a[2]; }
-      D = a[0] * Ul[0] + a[1] * Ul[1] + a[2] * Ul[2]; u = tau - (a[0] * pl[0] + a[1] * pl[1] + a[2] * pl[2]);
-    }
-    areal Di = (areal)1 / D;
-    for (int i = 0; i < 3; i++) { sh.AU[L][i] = (real)Ua[i]; sh.AU[L][3 + i] = (real)Ul[i]; }
-    sh.ADinv[L] = (real)Di; sh.Au[L] = (real)u;
+    const V3 a = ld3(sh.LA[L]);
+    V3 Ua, Ul; real D, u;
+    const real tau = -L_DAMPING[L] * sh.u[link_dof(L)];
+    if (jt == PIH_JT_REVOLUTE) { Ua = mul(A, a); Ul = tmul(B, a); D = dot(a, Ua); u = tau - dot(a, pa); }
+    else { Ua = mul(B, a); Ul = mul(C, a); D = dot(a, Ul); u = tau - dot(a, pl); }
+    const real Di = (real)1 / D;
+    st3(sh.AU[L], Ua); st3(sh.AU[L] + 3, Ul); sh.ADinv[L] = Di; sh.Au[L] = u;
     if (p < 0) continue;   // arm root: parent is the fixed world
     // I^a = I^A - U U^T / D
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { A[3 * i + j] -= Ua[i] * Ua[j] * Di; B[3 * i + j] -= Ua[i] * Ul[j] * Di; C[3 * i + j] -= Ul[i] * Ul[j] * Di; }
+    const V3 UaD = Di * Ua, UlD = Di * Ul;
+    A.xx -= UaD.x * Ua.x; A.yy -= UaD.y * Ua.y; A.zz -= UaD.z * Ua.z; A.xy -= UaD.x * Ua.y; A.xz -= UaD.x * Ua.z; A.yz -= UaD.y * Ua.z;
+    C.xx -= UlD.x * Ul.x; C.yy -= UlD.y * Ul.y; C.zz -= UlD.z * Ul.z; C.xy -= UlD.x * Ul.y; C.xz -= UlD.x * Ul.z; C.yz -= UlD.y * Ul.z;
+    B.m[0] -= UaD.x * Ul.x; B.m[1] -= UaD.x * Ul.y; B.m[2] -= UaD.x * Ul.z;
+    B.m[3] -= UaD.y * Ul.x; B.m[4] -= UaD.y * Ul.y; B.m[5] -= UaD.y * Ul.z;
+    B.m[6] -= UaD.z * Ul.x; B.m[7] -= UaD.z * Ul.y; B.m[8] -= UaD.z * Ul.z;
     // p^a = p^A + I^a c + U u / D
-    const areal ca[3] = {sh.a.CB[L][0], sh.a.CB[L][1], sh.a.CB[L][2]}, cl[3] = {sh.a.CB[L][3], sh.a.CB[L][4], sh.a.CB[L][5]};
-    areal ud = u * Di, qa[3], ql[3];
-    for (int i = 0; i < 3; i++) {
-      qa[i] = pa[i] + A[3 * i] * ca[0] + A[3 * i + 1] * ca[1] + A[3 * i + 2] * ca[2] + B[3 * i] * cl[0] + B[3 * i + 1] * cl[1] + B[3 * i + 2] * cl[2] + ud * Ua[i];
-      ql[i] = pl[i] + B[i] * ca[0] + B[3 + i] * ca[1] + B[6 + i] * ca[2] + C[3 * i] * cl[0] + C[3 * i + 1] * cl[1] + C[3 * i + 2] * cl[2] + ud * Ul[i];
-    }
-    // translate to the parent's origin: r = o_L - o_p ;  B' = B + [r]x C ;  A' = A + [r]x B^T - B' [r]x
-    const areal r[3] = {sh.AR[L][0], sh.AR[L][1], sh.AR[L][2]};
-    areal X[9], Bn[9], Y[9];
-    for (int j = 0; j < 3; j++) {   // columns: [r]x M  => column j = r x M[:,j]
-      areal bx = B[3 * j], by = B[3 * j + 1], bz = B[3 * j + 2];            // column j of B^T = row j of B
-      X[j] = r[1] * bz - r[2] * by; X[3 + j] = r[2] * bx - r[0] * bz; X[6 + j] = r[0] * by - r[1] * bx;
-      areal cx = C[j], cy = C[3 + j], cz = C[6 + j];
-      Bn[j] = B[j] + (r[1] * cz - r[2] * cy); Bn[3 + j] = B[3 + j] + (r[2] * cx - r[0] * cz); Bn[6 + j] = B[6 + j] + (r[0] * cy - r[1] * cx);
-    }
-    for (int i = 0; i < 3; i++) {   // rows: M [r]x => row i = M[i,:] x r
-      areal mx = Bn[3 * i], my = Bn[3 * i + 1], mz = Bn[3 * i + 2];
-      Y[3 * i] = my * r[2] - mz * r[1]; Y[3 * i + 1] = mz * r[0] - mx * r[2]; Y[3 * i + 2] = mx * r[1] - my * r[0];
-    }
-    areal T[27];
-    T[0] = A[0] + X[0] - Y[0]; T[1] = A[4] + X[4] - Y[4]; T[2] = A[8] + X[8] - Y[8];
-    T[3] = A[1] + (areal)0.5 * ((X[1] - Y[1]) + (X[3] - Y[3]));
-    T[4] = A[2] + (areal)0.5 * ((X[2] - Y[2]) + (X[6] - Y[6]));
-    T[5] = A[5] + (areal)0.5 * ((X[5] - Y[5]) + (X[7] - Y[7]));
-    for (int i = 0; i < 9; i++) T[6 + i] = Bn[i];
-    T[15] = C[0]; T[16] = C[4]; T[17] = C[8]; T[18] = C[1]; T[19] = C[2]; T[20] = C[5];
-    T[21] = qa[0] + (r[1] * ql[2] - r[2] * ql[1]); T[22] = qa[1] + (r[2] * ql[0] - r[0] * ql[2]); T[23] = qa[2] + (r[0] * ql[1] - r[1] * ql[0]);
-    T[24] = ql[0]; T[25] = ql[1]; T[26] = ql[2];
-    if (L == ANL - 1) { for (int i = 0; i < 27; i++) hold[i] = T[i]; }                    // finger 8: park until finger 7 is done
-    else if (L == ANL - 2) { for (int i = 0; i < 27; i++) carry[i] = T[i] + hold[i]; }    // finger 7: both fingers feed link 6
-    else { for (int i = 0; i < 27; i++) carry[i] = T[i]; }
+    const V3 ca = ld3(sh.a.CB[L]), cl = ld3(sh.a.CB[L] + 3);
+    const real ud = u * Di;
+    const V3 qa = pa + mul(A, ca) + mul(B, cl) + ud * Ua;
+    const V3 ql = pl + tmul(B, ca) + mul(C, cl) + ud * Ul;
+    // translate to the parent's origin: r = o_L - o_p ;  B' = B + [r]x C ;  A' = A + [r]x B^T - B' [r]x  (symmetric)
+    const V3 r = ld3(sh.AR[L]);
+    M3 X;     // [r]x B^T : column j = r x (row j of B)
+    { V3 c0 = cross(r, mk(B.m[0], B.m[1], B.m[2])), c1 = cross(r, mk(B.m[3], B.m[4], B.m[5])), c2 = cross(r, mk(B.m[6], B.m[7], B.m[8]));
+      X.m[0] = c0.x; X.m[3] = c0.y; X.m[6] = c0.z; X.m[1] = c1.x; X.m[4] = c1.y; X.m[7] = c1.z; X.m[2] = c2.x; X.m[5] = c2.y; X.m[8] = c2.z; }
+    M3 Bn;    // B + [r]x C : column j of [r]x C = r x (column j of C)
+    { V3 c0 = cross(r, mk(C.xx, C.xy, C.xz)), c1 = cross(r, mk(C.xy, C.yy, C.yz)), c2 = cross(r, mk(C.xz, C.yz, C.zz));
+      Bn.m[0] = B.m[0] + c0.x; Bn.m[3] = B.m[3] + c0.y; Bn.m[6] = B.m[6] + c0.z; Bn.m[1] = B.m[1] + c1.x; Bn.m[4] = B.m[4] + c1.y; Bn.m[7] = B.m[7] + c1.z;
+      Bn.m[2] = B.m[2] + c2.x; Bn.m[5] = B.m[5] + c2.y; Bn.m[8] = B.m[8] + c2.z; }
+    // Y = B' [r]x : row i = (row i of B') x r
+    const V3 y0 = cross(mk(Bn.m[0], Bn.m[1], Bn.m[2]), r), y1 = cross(mk(Bn.m[3], Bn.m[4], Bn.m[5]), r), y2 = cross(mk(Bn.m[6], Bn.m[7], Bn.m[8]), r);
+    Acc T;
+    T.A.xx = A.xx + X.m[0] - y0.x; T.A.yy = A.yy + X.m[4] - y1.y; T.A.zz = A.zz + X.m[8] - y2.z;
+    T.A.xy = A.xy + (real)0.5 * ((X.m[1] - y0.y) + (X.m[3] - y1.x));
+    T.A.xz = A.xz + (real)0.5 * ((X.m[2] - y0.z) + (X.m[6] - y2.x));
+    T.A.yz = A.yz + (real)0.5 * ((X.m[5] - y1.z) + (X.m[7] - y2.y));
+    T.B = Bn; T.C = C;
+    T.pa = qa + cross(r, ql); T.pl = ql;
+    if (L == ANL - 1) hold = T;                                   // finger 8: park until finger 7 is done
+    else if (L == ANL - 2) {                                      // finger 7: both fingers feed link 6
+      carry = T;
+      carry.A.xx += hold.A.xx; carry.A.yy += hold.A.yy; carry.A.zz += hold.A.zz; carry.A.xy += hold.A.xy; carry.A.xz += hold.A.xz; carry.A.yz += hold.A.yz;
+      carry.C.xx += hold.C.xx; carry.C.yy += hold.C.yy; carry.C.zz += hold.C.zz; carry.C.xy += hold.C.xy; carry.C.xz += hold.C.xz; carry.C.yz += hold.C.yz;
+      for (int i = 0; i < 9; i++) carry.B.m[i] += hold.B.m[i];
+      carry.pa = carry.pa + hold.pa; carry.pl = carry.pl + hold.pl;
+    } else carry = T;
   }
   w.stamp(10);
   // outward sweep: accelerations (wave-uniform).  VW/VV are reused to carry (alpha, acc) of each link.
