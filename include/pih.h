@@ -66,7 +66,7 @@ typedef struct pih_config {
   int32_t auto_reset;         /* 1: finished envs are reset inside pih_step */
   int32_t enable_self_collision;
   int32_t debug;              /* 1: fill the debug buffer each step */
-  int32_t reserved;
+  int32_t schedule;           /* 1 (default): longest-job-first dispatch order from the previous step's contact counts; 0: block i = env i */
   uint64_t seed;
   float dt;                   /* 1/240 */
   float residual_threshold;   /* 1e-7 */

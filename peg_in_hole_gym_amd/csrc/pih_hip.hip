@@ -13,12 +13,36 @@ using namespace pih;
 // ------------------------------------------------------------------------------------------------ kernels
 // state: float[n][256] (env-major records: the 64 lanes of the env's wave read/write consecutive words, so every
 // access is a fully coalesced 256 B segment).
+// Longest-job-first dispatch order.  The cost of an env-step grows ~linearly with its contact count (each contact is one
+// 3x3 PGS block per iteration), and at 4096 envs there are only two rounds of resident waves, so a heavy env that starts
+// late leaves most of the chip idle at the tail.  This single-workgroup counting sort orders the envs by the contact count
+// of their PREVIOUS step (descending); pih_step_kernel maps blockIdx through it.  Results do not depend on block order.
+__global__ void __launch_bounds__(1024) pih_order_kernel(const float* __restrict__ state, int* __restrict__ order, int n) {
+  __shared__ int hist[64], base[64];
+  const int t = threadIdx.x;
+  if (t < 64) hist[t] = 0;
+  __syncthreads();
+  for (int e = t; e < n; e += 1024) {
+    int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
+    k = k < 0 ? 0 : (k > 63 ? 63 : k);
+    atomicAdd(&hist[63 - k], 1);          // bin 0 = most contacts
+  }
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int b = 0; b < 64; b++) { base[b] = acc; acc += hist[b]; } }
+  __syncthreads();
+  for (int e = t; e < n; e += 1024) {
+    int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
+    k = k < 0 ? 0 : (k > 63 ? 63 : k);
+    order[atomicAdd(&base[63 - k], 1)] = e;
+  }
+}
+
 __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
                                                       float* __restrict__ obs, float* __restrict__ reward,
                                                       unsigned char* __restrict__ done, float* __restrict__ dbg,
-                                                      float* __restrict__ ovf) {
+                                                      float* __restrict__ ovf, const int* __restrict__ order) {
   __shared__ Shared sh;
-  const int env = blockIdx.x, lane = threadIdx.x;
+  const int env = order ? order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
   Wave w; w.l = lane; w.counter = 0;
   float* rec = state + (size_t)env * PIH_STATE_WORDS;
 #pragma unroll
@@ -113,6 +137,7 @@ struct pih_handle {
   float* state = nullptr;
   float* dbg = nullptr;
   float* ovf = nullptr;     // spill area for contacts beyond the LDS-resident CL (rarely touched)
+  int* order = nullptr;     // longest-job-first block -> env map (pih_order_kernel)
   std::string err;
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // event pairs bracketing each step launch
@@ -143,7 +168,7 @@ extern "C" {
 void pih_default_config(pih_config* c) {
   memset(c, 0, sizeof *c);
   c->n_envs = 1; c->env_index0 = 0; c->mode = 0; c->solver_iters = 50; c->ik_iters = 20; c->max_episode_steps = 2227;
-  c->auto_reset = 0; c->enable_self_collision = 1; c->debug = 0; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
+  c->auto_reset = 0; c->enable_self_collision = 1; c->debug = 0; c->schedule = 1; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
   c->erp = 0.2f; c->warmstart = 0.85f; c->contact_margin = 0.005f; c->linear_slop = 1e-5f; c->ik_damping = 0.5f; c->ik_residual = 1e-4f;
   c->dv = 2.0f / 240.0f;
 }
@@ -161,6 +186,7 @@ int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** ou
   HIPCHK(h, hipMalloc(&h->state, nb));
   HIPCHK(h, hipMemset(h->state, 0, nb));
   HIPCHK(h, hipMalloc(&h->ovf, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
+  if (cfg->schedule) HIPCHK(h, hipMalloc(&h->order, (size_t)cfg->n_envs * sizeof(int)));
   if (cfg->debug) { HIPCHK(h, hipMalloc(&h->dbg, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); HIPCHK(h, hipMemset(h->dbg, 0, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); }
   float* offd = nullptr;
   if (offsets_host) {
@@ -182,6 +208,7 @@ int pih_destroy(pih_handle* h) {
   if (h->state) hipFree(h->state);
   if (h->dbg) hipFree(h->dbg);
   if (h->ovf) hipFree(h->ovf);
+  if (h->order) hipFree(h->order);
   delete h;
   return 0;
 }
@@ -195,6 +222,7 @@ int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, void* stream) {
 }
 
 static int launch_step(pih_handle* h, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t s) {
+  if (h->order) hipLaunchKernelGGL(pih_order_kernel, dim3(1), dim3(1024), 0, s, h->state, h->order, h->cfg.n_envs);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->timing) {
     if (h->ev_used == h->ev.size()) {
@@ -205,7 +233,7 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
     e0 = h->ev[h->ev_used].first; e1 = h->ev[h->ev_used].second; h->ev_used++;
     HIPCHK(h, hipEventRecord(e0, s));
   }
-  hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->ovf);
+  hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->ovf, h->order);
   if (h->timing) HIPCHK(h, hipEventRecord(e1, s));
   HIPCHK(h, hipGetLastError());
   return 0;
