@@ -43,7 +43,7 @@ def pmc_traffic(n_envs):
     return None, None
 
 
-def cpu_baseline(envs_sample=256, steps=40):
+def cpu_baseline(envs_sample=4096, steps=24):
     """Oracle ("port") on the host cores, all threads, bounded sample: envs_sample envs x steps steps."""
     import numpy as np
     from oracle import oracle as O
@@ -53,7 +53,7 @@ def cpu_baseline(envs_sample=256, steps=40):
     o = O.Oracle(envs_sample, omp=True, auto_reset=1, max_episode_steps=2227)
     rng = np.random.default_rng(1234)
     acts = rng.uniform(-1, 1, (steps + 5, envs_sample, 4))
-    for t in range(5):
+    for t in range(5):        # warm-up (the pipes are still in free fall here: cheapest steps, like the GPU run's start)
         o.step(acts[t])
     t0 = time.perf_counter()
     for t in range(steps):
