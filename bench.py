@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (1-GPU box, gloo backend)")
     args = ap.parse_args()
 
     import torch
@@ -84,8 +86,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.share_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -139,7 +146,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Panda peg-in-hole, %d parallel envs per GPU, random actions U(-1,1), dt=1/240, auto-reset" % n,
-                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + RCCL all-gather(obs)")},
+                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + %s all-gather(obs)" % ("RCCL" if args.backend == "nccl" else args.backend))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (ALG_BYTES_PER_ENV_STEP * n),
                          "kernel": "pih_step_kernel", "kernel_avg_ms": kernel_ms, "launches": launches,
