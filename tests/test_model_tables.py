@@ -1,0 +1,67 @@
+"""The committed model header (include/pih_model.h) against the reference's own asset files, parsed by tools/urdf_tables.py.
+Runs only where /root/reference exists (the build container); on the GPU box it is skipped."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "peg_in_hole_gym")), reason="reference assets not present")
+
+
+def _macro(name):
+    hdr = open(os.path.join(ROOT, "include", "pih_model.h")).read()
+    body = re.search(r"#define %s (.*)" % name, hdr).group(1).split("/*")[0]
+    return np.array(eval(body.replace("{", "[").replace("}", "]")), dtype=float)
+
+
+@pytest.fixture(scope="module")
+def T():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import urdf_tables
+    return urdf_tables
+
+
+def test_pipe_tables_match_pipe_urdf(T):
+    p = T.pipe_tables(REF)
+    tfix, axis, mass, com, mu = _macro("PIH_LINK_TFIX")[9:], _macro("PIH_LINK_AXIS")[9:], _macro("PIH_LINK_MASS")[9:], _macro("PIH_LINK_COM")[9:], _macro("PIH_LINK_MU")[9:]
+    jx = np.array(p["joint_xyz"])
+    # object link 1 = pipe_link2: its joint sits on link1, which sits at joint0 (fixed) of link0
+    np.testing.assert_allclose(tfix[1], jx[0] + jx[1], atol=1e-15)
+    np.testing.assert_allclose(tfix[2:], jx[2:], atol=1e-15)
+    np.testing.assert_allclose(axis[1:], np.array(p["joint_axis"])[1:], atol=0)
+    assert abs(mass[0] - (p["mass"][0] + p["mass"][1])) < 1e-15 and np.allclose(mass[1:], p["mass"][2:])
+    # merged root COM = mass-weighted (link0 com, link1 com shifted by the fixed joint)
+    c1 = jx[0] + np.array(p["com"][1])
+    np.testing.assert_allclose(com[0], (p["mass"][0] * np.array(p["com"][0]) + p["mass"][1] * c1) / mass[0], atol=1e-15)
+    np.testing.assert_allclose(com[1:], np.array(p["com"])[2:], atol=1e-15)
+    assert [f if f is not None else 0.5 for f in p["friction"]][2:] == mu[1:].tolist() and mu[0] == p["friction"][0] == p["friction"][1]
+    # AABB box inertia of an unmerged link, and the rope radius / cylinder placement
+    np.testing.assert_allclose(p["aabb_ext"], [0.022, 0.062, 0.022], atol=1e-12)
+    I = _macro("PIH_LINK_INERTIA")[10]
+    np.testing.assert_allclose(I[:3], T.box_inertia_diag(0.0111, p["aabb_ext"]), rtol=1e-12)
+    assert abs(_macro("PIH_PIPE_RADIUS") - (p["aabb_ext"][0] - 0.002) / 2) < 1e-15
+    assert all(abs(c[1] - 0.03) < 1e-15 for c in p["collision_xyz"])        # every cylinder spans y in [0, 6 cm] of its link
+
+
+def test_hole_tables_match_obj(T):
+    h = T.hole_tables(REF)
+    assert abs(_macro("PIH_HOLE_RIN") - h["rin"]) < 1e-6 and abs(_macro("PIH_HOLE_ROUT") - h["rout"]) < 1e-6
+    assert abs(_macro("PIH_HOLE_HALFLEN") - h["halflen"]) < 1e-12
+
+
+def test_ur5_tables_match_ur5_urdf(T):
+    u = T.ur5_tables(REF)
+    np.testing.assert_allclose(_macro("PIH_UR5_TFIX"), u["xyz"], atol=0)
+    np.testing.assert_allclose(_macro("PIH_UR5_AXIS"), u["axis"], atol=0)
+    np.testing.assert_allclose(_macro("PIH_UR5_BASE_T"), u["base_xyz"], atol=0)
+    np.testing.assert_allclose(_macro("PIH_UR5_EE_T"), u["ee_xyz"], atol=0)
+    np.testing.assert_allclose(_macro("PIH_UR5_EFFORT"), u["effort"], atol=0)
+    R = _macro("PIH_UR5_RFIX")
+    for i, rpy in enumerate(u["rpy"]):
+        np.testing.assert_allclose(R[i].reshape(3, 3), T.rpy_matrix(*rpy), atol=1e-15)
+    np.testing.assert_allclose(_macro("PIH_UR5_EE_R").reshape(3, 3), T.rpy_matrix(*u["ee_rpy"]), atol=1e-15)
+    assert u["rpy"][0][2] == 3.14 and u["rpy"][1][1] == 1.6 and u["damping"] == [0.5] * 6       # the literal 3.14 / 1.6 of the file

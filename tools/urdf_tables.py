@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""URDF / OBJ -> model-table reader (offline tool).
+
+Reads a URDF with xml.etree, merges fixed joints, applies pybullet's `globalScaling`, and derives what the kernels need:
+joint origins / axes / limits / damping, link masses / inertial origins / lateral friction, and -- because the reference
+loads without URDF_USE_INERTIA_FROM_FILE -- the collision AABB from the referenced OBJ mesh (for the box-inertia rule of
+SURVEY.md App. C).  It is used to CHECK the committed include/pih_model.h against the reference's asset files
+(tests/test_model_tables.py; only where /root/reference exists) and is the seed of a general custom-task importer.
+Nothing here runs on the GPU box.
+"""
+import math
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+
+def _floats(s, n=3, default=0.0):
+    if s is None:
+        return [default] * n
+    return [float(x) for x in s.split()]
+
+
+def rpy_matrix(r, p, y):
+    cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]]); Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def obj_vertices(path):
+    v = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("v "):
+                v.append([float(x) for x in line.split()[1:4]])
+    return np.array(v)
+
+
+class Urdf:
+    def __init__(self, path, scale=1.0):
+        self.path = path
+        self.scale = scale
+        root = ET.parse(path).getroot()
+        self.links = {}
+        for l in root.findall("link"):
+            d = {"name": l.get("name"), "mass": 0.0, "com": [0, 0, 0], "friction": None, "collision": None}
+            ine = l.find("inertial")
+            if ine is not None:
+                m = ine.find("mass")
+                d["mass"] = float(m.get("value")) if m is not None else 0.0
+                origins = ine.findall("origin")
+                if origins:
+                    d["com"] = [x * scale for x in _floats(origins[-1].get("xyz"))]     # the last <origin> wins, as in urdfdom
+            c = l.find("contact")
+            if c is not None and c.find("lateral_friction") is not None:
+                d["friction"] = float(c.find("lateral_friction").get("value"))
+            col = l.find("collision")
+            if col is not None:
+                o = col.find("origin")
+                mesh = col.find("geometry").find("mesh") if col.find("geometry") is not None else None
+                d["collision"] = {"xyz": [x * scale for x in _floats(o.get("xyz") if o is not None else None)],
+                                  "mesh": mesh.get("filename") if mesh is not None else None}
+            self.links[d["name"]] = d
+        self.joints = []
+        for j in root.findall("joint"):
+            o = j.find("origin")
+            ax = j.find("axis")
+            lim = j.find("limit")
+            dyn = j.find("dynamics")
+            self.joints.append({
+                "name": j.get("name"), "type": j.get("type"), "parent": j.find("parent").get("link"), "child": j.find("child").get("link"),
+                "xyz": [x * scale for x in _floats(o.get("xyz") if o is not None else None)],
+                "rpy": _floats(o.get("rpy") if o is not None else None),
+                "axis": _floats(ax.get("xyz")) if ax is not None else [1, 0, 0],
+                "effort": float(lim.get("effort")) if lim is not None and lim.get("effort") else None,
+                "lower": lim.get("lower") if lim is not None else None, "upper": lim.get("upper") if lim is not None else None,
+                "damping": float(dyn.get("damping")) if dyn is not None and dyn.get("damping") else 0.0})
+
+    def mesh_aabb_extents(self, link, margin=0.001):
+        """Scaled AABB extents (+ 2 * collision margin) of the link's collision mesh."""
+        c = self.links[link]["collision"]
+        p = os.path.normpath(os.path.join(os.path.dirname(self.path), c["mesh"]))
+        v = obj_vertices(p) * self.scale
+        return (v.max(0) - v.min(0)) + 2 * margin
+
+    def chain(self, root_link):
+        """Joints in order down a serial chain starting at root_link."""
+        out, cur = [], root_link
+        by_parent = {j["parent"]: j for j in self.joints}
+        while cur in by_parent:
+            j = by_parent[cur]
+            out.append(j)
+            cur = j["child"]
+        return out
+
+
+def box_inertia_diag(m, ext):
+    lx, ly, lz = ext
+    return [m / 12 * (ly * ly + lz * lz), m / 12 * (lx * lx + lz * lz), m / 12 * (lx * lx + ly * ly)]
+
+
+def pipe_tables(ref_root):
+    """What include/pih_model.h encodes for the pipe (envs/assets/urdf/pipe.urdf, globalScaling 0.01)."""
+    u = Urdf(os.path.join(ref_root, "peg_in_hole_gym/envs/assets/urdf/pipe.urdf"), scale=0.01)
+    ch = u.chain("pipe_link0")
+    assert [j["type"] for j in ch] == ["fixed"] + ["continuous"] * 23
+    ext = u.mesh_aabb_extents("pipe_link0")
+    links = ["pipe_link0"] + [j["child"] for j in ch]      # by chain order: link 16 is named "pipe_link10.0111" in the file
+    return {"joint_xyz": [j["xyz"] for j in ch], "joint_axis": [j["axis"] for j in ch], "mass": [u.links[l]["mass"] for l in links],
+            "com": [u.links[l]["com"] for l in links], "friction": [u.links[l]["friction"] for l in links], "aabb_ext": ext.tolist(),
+            "collision_xyz": [u.links[l]["collision"]["xyz"] for l in links]}
+
+
+def hole_tables(ref_root):
+    v = obj_vertices(os.path.join(ref_root, "peg_in_hole_gym/envs/assets/obj/cylinder_base.obj")) * 0.016
+    rad = np.sqrt(v[:, 0] ** 2 + v[:, 2] ** 2)
+    return {"rin": float(rad.min()), "rout": float(rad.max()), "halflen": float(np.abs(v[:, 1]).max())}
+
+
+def ur5_tables(ref_root):
+    u = Urdf(os.path.join(ref_root, "peg_in_hole_gym/envs/assets/urdf/ur5.urdf"))
+    ch = u.chain("world")
+    rev = [j for j in ch if j["type"] == "revolute"]
+    fixed = [j for j in ch if j["type"] == "fixed"]
+    return {"base_xyz": fixed[0]["xyz"], "rpy": [j["rpy"] for j in rev], "xyz": [j["xyz"] for j in rev], "axis": [j["axis"] for j in rev],
+            "effort": [j["effort"] for j in rev], "damping": [j["damping"] for j in rev], "ee_rpy": fixed[-1]["rpy"], "ee_xyz": fixed[-1]["xyz"],
+            "mass": [u.links[j["child"]]["mass"] for j in rev]}
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    print(json.dumps({"pipe": pipe_tables(ref), "hole": hole_tables(ref), "ur5": ur5_tables(ref)}, indent=1)[:3000])
