@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--mode", default="action", choices=["action", "scripted"], help="action = panda_execute per step (headline); scripted = the reference's grasp-and-insert state machine")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (1-GPU box, gloo backend)")
     args = ap.parse_args()
@@ -97,7 +98,8 @@ def main():
     torch.cuda.set_device(dev)
 
     n = args.envs
-    env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, max_episode_steps=2227, seed=args.seed)
+    mode_kw = dict(mode=1, dv=0.05) if args.mode == "scripted" else {}
+    env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, max_episode_steps=2227, seed=args.seed, **mode_kw)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = min(args.steps + args.warmup, 1024)
     actions = torch.rand(pool, n, 4, device=dev, generator=gen) * 2 - 1       # resident in HBM before the timed region
@@ -145,7 +147,7 @@ def main():
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Panda peg-in-hole, %d parallel envs per GPU, random actions U(-1,1), dt=1/240, auto-reset" % n,
+            "config": {"workload": "Panda peg-in-hole, %d parallel envs per GPU, %s, dt=1/240, auto-reset" % (n, "random actions U(-1,1)" if args.mode == "action" else "scripted grasp-and-insert episodes"),
                        "envs_per_gpu": n, "total_envs": total_envs, "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + %s all-gather(obs)" % ("RCCL" if args.backend == "nccl" else args.backend))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (ALG_BYTES_PER_ENV_STEP * n),

@@ -609,8 +609,25 @@ static void collide(const piho_config* c, Env* E, const LinkKin* K) {
     int L = ANL + SAMP_LINK[i];
     add_contact(E, L, -1, 100 + i, p, n, depth, L_MU[L] * PIH_HOLE_MU);
   }
-  /* finger pad boxes; at most PIHO_CAMAX contacts may involve the arm */
+  /* p7 attach (envs/peg_in_hole.py:99-104: createConstraint on entering state 4, removeConstraint on entering 7), restated
+   * as a BALL JOINT between the grasp point of the grasped pipe link (childFramePosition = random_vector) and the origin of
+   * the grasp-target frame (parentFramePosition = 0): one "contact" whose three rows are bilateral (mu < 0 marks it).  The
+   * reference's JOINT_GEAR between a 0-DOF link and a pipe link has no usable semantics (SURVEY.md hard part 5). */
   int nca = 0;
+  if (c->mode == 1 && E->s[PIHO_S_FSM] >= 4 && E->s[PIHO_S_FSM] <= 6) {
+    int g = (int)E->s[PIHO_S_GRASP];
+    const LinkKin* k = g == 0 ? &K[ANL] : &K[NL - 1];
+    v3 loc = {0, (g == 0 ? 0.045 : 0.015) + E->s[PIHO_S_RANDY], 0}, a1, ee, d; double eR[9];
+    m_mulv(a1, k->R, loc); v_add(a1, a1, k->o);
+    ee_pose(K, ee, eR);
+    v_sub(d, a1, ee);
+    double dist = v_norm(d);
+    v3 n = {1, 0, 0}, p;
+    if (dist > 1e-9) v_set(n, d[0] / dist, d[1] / dist, d[2] / dist);
+    v_add(p, a1, ee); v_set(p, 0.5 * p[0], 0.5 * p[1], 0.5 * p[2]);
+    nca += add_contact(E, g == 0 ? ANL : NL - 1, PIH_EE_PARENT, 2000, p, n, dist, -1.0);
+  }
+  /* finger pad boxes; at most PIHO_CAMAX contacts may involve the arm */
   for (int f = 0; f < 2; f++) {
     const LinkKin* kf = &K[PIH_FINGER_LINK0 + f];
     v3 bc; m_mulv(bc, kf->R, FBOX_C[f]); v_add(bc, bc, kf->o);
@@ -794,7 +811,8 @@ static void step_env(piho_handle* h, int e, const double* action, double* obs, d
       if (rep == 0) {
         double pen = ct->depth + c->linear_slop;
         double vb = pen > 0 ? -pen / dt : -c->erp * pen / dt;
-        r->rhs = (vb - ju) * r->dinv; r->lo = 0; r->hi = 1e30; r->fparent = -1;
+        if (ct->mu < 0) vb = -c->erp * ct->depth / dt;          /* attach: close the gap with ERP, both signs allowed */
+        r->rhs = (vb - ju) * r->dinv; r->lo = ct->mu < 0 ? -1e30 : 0; r->hi = 1e30; r->fparent = -1;
         for (int k = 0; k < E->ncache; k++) if (E->cache_key[k] == ct->key) { r->lambda = c->warmstart * E->cache_lambda[k]; break; }
       } else { r->rhs = -ju * r->dinv; r->fparent = row_n0 + 3 * i; r->mu = ct->mu; }
     }
@@ -808,9 +826,12 @@ static void step_env(piho_handle* h, int e, const double* action, double* obs, d
     for (int i = 0; i < nr; i++) {
       Row* r = &rows[i];
       if (r->fparent >= 0) {
-        double tot = rows[r->fparent].lambda;
-        if (!(tot > 0)) continue;
-        r->lo = -r->mu * tot; r->hi = r->mu * tot;
+        if (r->mu < 0) { r->lo = -1e30; r->hi = 1e30; }          /* bilateral (attach) rows */
+        else {
+          double tot = rows[r->fparent].lambda;
+          if (!(tot > 0)) continue;
+          r->lo = -r->mu * tot; r->hi = r->mu * tot;
+        }
       }
       double jd = 0; for (int k = 0; k < ND; k++) jd += r->J[k] * dv[k];
       double dl = r->rhs - jd * r->dinv, sum = r->lambda + dl;

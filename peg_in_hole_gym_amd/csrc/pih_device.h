@@ -508,8 +508,29 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
     int slot = w.alloc(valid);
     if (valid && slot < CMAX) emit(slot, L, -1, 100 + i, p, n, depth, L_MU[L] * (real)PIH_HOLE_MU);
   });
-  // finger pad boxes (arm links 7, 8)
+  // p7 attach (envs/peg_in_hole.py:99-104), restated as a ball joint between the grasp point of the grasped pipe link
+  // (childFramePosition = random_vector) and the grasp-target origin (parentFramePosition = 0), active in FSM states 4..6:
+  // one contact whose three rows are bilateral (mu < 0 marks it); emitted before the finger contacts so it is never dropped
   int nca = 0;
+  {
+    const bool attached = P.mode == 1 && sh.S[PIH_S_FSM] >= 4 && sh.S[PIH_S_FSM] <= 6;
+    const int before = w.alloc_count();
+    w.par_all(1, [&](int i, bool in) {
+      bool valid = in && i == 0 && attached;
+      int slot = w.alloc(valid);
+      if (valid && slot < CMAX) {
+        int g = (int)sh.S[PIH_S_GRASP];
+        int L = g == 0 ? ANL : NL - 1;
+        V3 a1 = ld3(sh.LO[L]) + mul(ldm(sh.a.LR[L]), mk(0, (g == 0 ? (real)0.045 : (real)0.015) + sh.S[PIH_S_RANDY], 0));
+        V3 ee; M3 eR; ee_pose(sh, ee, eR);
+        V3 d = a1 - ee; real dist = norm(d);
+        V3 n = dist > (real)1e-9 ? ((real)1 / dist) * d : mk(1, 0, 0);
+        emit(slot, L, PIH_EE_PARENT, 2000, (real)0.5 * (a1 + ee), n, dist, (real)-1);
+      }
+    });
+    nca += w.alloc_count() - before;
+  }
+  // finger pad boxes (arm links 7, 8)
   for (int f = 0; f < 2; f++) {
     const int LF = PIH_FINGER_LINK0 + f;
     M3 Rf = ldm(sh.a.LR[LF]); V3 bc = ld3(sh.LO[LF]) + mul(Rf, ld3(FBOX_C[f])); V3 bh = ld3(FBOX_H);
@@ -919,6 +940,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
     if (k == 0) {
       real pen = sh.c_depth[c] + P.slop;
       real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
+      if (sh.c_mu[c] < 0) vb = -P.erp * sh.c_depth[c] / dt;   // attach: close the gap with ERP, both signs allowed
       rhs = (vb - ju) * di;
       int ncache = (int)sh.S[PIH_S_CACHE_N]; real key = (real)sh.c_key[c];
       for (int i = 0; i < ncache; i++) if (sh.S[PIH_S_CACHE_KEY + i] == key) { lam = P.warm * sh.S[PIH_S_CACHE_LAMBDA + i]; break; }
@@ -1058,7 +1080,8 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       for (int k = 0; k < 3; k++) {
         int row = 3 * c + k;
         real lo = 0, hi = PIH_BIG;
-        if (k > 0) { real tot = sh.r_lam[3 * c]; if (!(tot > 0)) continue; hi = R[5] * tot; lo = -hi; }
+        if (R[5] < 0) lo = -PIH_BIG;                                   // bilateral (attach) rows
+        else if (k > 0) { real tot = sh.r_lam[3 * c]; if (!(tot > 0)) continue; hi = R[5] * tot; lo = -hi; }
         V3 dir = ld3(R + 8 + 4 * k);
         real jd = 0;
         for (int d = 0; d < ND; d++) jd += jac_entry(geo[d], sh.c_la[c], sh.c_lb[c], p, dir) * du[d];
@@ -1181,13 +1204,14 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       rows012_total3(jd0, jd1, jd2);          // valid in lanes 32..47 from here; the scalar chain below runs in plain VGPRs
       const real l0 = r.q[6].z, l1 = r.q[6].w, l2 = r.q[7].x;
       const real di0 = r.q[2].w, di1 = r.q[3].w, di2 = r.q[4].w;
+      const bool bil = mu < 0;                  // attach rows: all three bilateral
       real s0 = l0 + (r.q[5].x - jd0 * di0);
-      s0 = max_(s0, (real)0);
+      s0 = max_(s0, bil ? -PIH_BIG : (real)0);
       real dl0 = s0 - l0;
       worstc = max_(worstc, dl0 * dl0 - r.q[7].y);
       real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
-      if (rdlane(s0, 32) > 0) {               // wave-uniform branch
-        real hi = mu * s0;
+      if (rdlane(s0, 32) > 0 || rdlane(mu, 32) < 0) {   // wave-uniform branch
+        real hi = bil ? PIH_BIG : mu * s0;
         jd1 += r.q[5].w * dl0;
         s1 = l1 + (r.q[5].y - jd1 * di1); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
         worstc = max_(worstc, dl1 * dl1 - r.q[7].z);

@@ -208,8 +208,8 @@ def test_scripted_mode_on_gpu(torch_mod, oracle_mod):
     g2 = _gpu(N, **kw)
     a = np.zeros((N, 4)); at = torch.zeros(N, 4)
     errs = []
-    for t in range(1150):
-        check = t < 100 or 560 <= t < 660 or 1020 <= t < 1150
+    for t in range(1350):
+        check = t < 100 or 560 <= t < 660 or 1020 <= t < 1150 or 1262 <= t < 1350      # last window: attach constraint active
         if check:
             _to_gpu_state(torch, g2, o.get_state())
         o.step(a)
