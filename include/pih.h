@@ -11,6 +11,8 @@
  *   pih_reset     replaces  envs/base_env.py:84-94 + envs/peg_in_hole.py:227-274 (loadURDF/resetJointState scene build)
  *   pih_ik / pih_ik_ur5  replace  p.calculateInverseKinematics stand-alone for the Panda / UR5 chain
  *                           (envs/utils.py:67,79; envs/meta_env.py:92,104)
+ *   pih_render    replaces  p.computeViewMatrix / computeProjectionMatrixFOV / getCameraImage of PegInHole.render
+ *                           (envs/peg_in_hole.py:276-304) with an analytic ray caster over the primitive scene
  *   pih_get_state replaces  p.getLinkState / p.getJointState / (north_star) getContactPoints normal force read-backs
  *
  * Conventions: every call returns 0 on success, <0 on error (pih_last_error gives the text).  All *_dev pointers
@@ -44,6 +46,7 @@ enum {
   PIH_S_NCONTACT = 106,
   PIH_S_PGS_ITERS = 107,   /* PGS iterations actually executed in the last step */
   PIH_S_EE = 108,          /* world position of the grasp-target frame (pybullet link 11) after the last step / reset (3) */
+  PIH_S_GRASP_ANGLE = 111, /* scripted mode: atan2 of the rotated grasp offset when the state machine entered state 2 (envs/peg_in_hole.py:72) */
   PIH_S_CACHE_N = 128, PIH_S_CACHE_KEY = 129, PIH_S_CACHE_LAMBDA = 129 + 48
 };
 
@@ -99,6 +102,16 @@ int pih_set_state(pih_handle* h, int field, const void* in_dev, void* stream);
 int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream);
 /* the same for the UR5 chain of envs/assets/urdf/ur5.urdf (ur_execute, envs/utils.py:70-82): q0/qout float[n,6] */
 int pih_ik_ur5(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream);
+/* wrist camera of PegInHole.render (envs/peg_in_hole.py:276-304; eye = link 11, looking straight down, fov 60, near 0.001,
+ * far 1000; the reference uses 300 x 300): out_dev float[env_count, height, width, 4] = (OpenGL depth-buffer value, r, g, b)
+ * for envs env_begin .. env_begin+env_count-1, from the CURRENT state.  RGB is a flat value per object (table 153, pipe and
+ * hole 232, fingers 77, background 255, the reference's uint8 scale): TinyRenderer's shading is not reproduced.  out_dev must be 16-byte aligned. */
+int pih_render(pih_handle* h, float* out_dev, int width, int height, int env_begin, int env_count, void* stream);
+/* grasp-rectangle label images of random_grasp (envs/peg_in_hole.py:72-99,116) from the angle each env recorded when its
+ * state machine entered state 2 (PIH_S_GRASP_ANGLE): out_dev float[env_count, 4, size, size] = pos (50 inside the rectangle),
+ * sin(2 angle), cos(2 angle), width in pixels; meta_dev (may be NULL) float[env_count, 5] = x, y, angle [deg], width, length.
+ * The reference rasterises with skimage.draw.polygon (absent here: parity unpinned); restated as its even-odd crossing test. */
+int pih_grasp_labels(pih_handle* h, float* out_dev, float* meta_dev, int size, int env_begin, int env_count, void* stream);
 /* kernel timing with HIP events on `stream`: average ms per pih_step launch since the last call with reset=1 */
 int pih_timing(pih_handle* h, int reset, double* avg_ms_out, int64_t* launches_out);
 int pih_set_timing(pih_handle* h, int enable);

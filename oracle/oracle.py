@@ -114,6 +114,11 @@ class Oracle:
     def ncontacts(self):
         n = np.zeros(self.n, dtype=np.int32); self.L.piho_get_ncontacts(self.h, n.ctypes.data_as(C.POINTER(C.c_int32))); return n
 
+    def render(self, W=300, H=300):
+        out = np.zeros((self.n, H, W, 4))
+        self.L.piho_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        self.L.piho_render(self.h, W, H, _dp(out)); return out
+
     def debug_contacts(self, env=0):
         out = np.zeros((CMAX, 12)); k = self.L.piho_debug_contacts(self.h, env, _dp(out)); return out[:k]
 
@@ -181,6 +186,14 @@ def quat_from_euler(rpy):
 
 def euler_from_quat(q):
     q = np.ascontiguousarray(q, dtype=np.float64); r = np.zeros(3); lib().piho_euler_from_quat(_dp(q), _dp(r)); return r
+
+
+def grasp_labels(angle, S=300):
+    """label images + [x, y, angle_deg, width, length] of random_grasp (envs/peg_in_hole.py:72-99, 116)"""
+    L = lib()
+    out = np.zeros((4, S, S)); meta = np.zeros(5)
+    L.piho_grasp_labels.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.piho_grasp_labels(float(angle), S, _dp(out), _dp(meta)); return out, meta
 
 
 def fsm_trace(n_steps, dt=1.0 / 240):

@@ -707,10 +707,12 @@ static void controller(const piho_config* c, Env* E, const double* action, const
     for (int i = 0; i < 9; i++) { mt_posctl[i] = 1; mt_kp[i] = 1.0; mt_target[i] = s[PIHO_S_TARGET + i]; mt_maximp[i] = 100000.0 * dt; }
   } else {
     /* random_grasp loop body, envs/peg_in_hole.py:53-112 */
+    int st_prev = (int)s[PIHO_S_FSM];
     int st = piho_fsm_update(&s[PIHO_S_FSM], &s[PIHO_S_FSMT], dt);
     double tip[7]; tip_pose(E, K, tip);
     v3 rv0 = {0, s[PIHO_S_RANDY], 0}, rv, tpos, tp;
     piho_rotate_vector(rv0, tip + 3, rv); v_add(tpos, tip, rv);
+    if (st == 2 && st_prev != 2) s[PIHO_S_GRASP_ANGLE] = atan2(rv[1], rv[0]);   /* label angle, envs/peg_in_hole.py:72 */
     piho_vel_constraint(eep, tpos, c->dv, tp);                               /* grasp_process :125 */
     double eul[3]; piho_euler_from_quat(tip + 3, eul);
     double rpy[3], tq[4], qs[9]; int do_ik = 0;
@@ -901,6 +903,129 @@ void piho_step(piho_handle* h, const double* actions, double* obs, double* rewar
     }
     step_env(h, e, actions + 4 * e, obs + 5 * e, reward + e, done + e);
   }
+}
+
+/* ------------------------------------------------------------------------------------------ camera (p12) */
+/* PegInHole.render (envs/peg_in_hole.py:276-304): eye = position of link 11, target = eye - (0,0,10), up = (0,1,0), fov 60,
+ * aspect 1, near 0.001, far 1000, 300x300; result = concat(depth buffer, rgb).  TinyRenderer is restated as an ANALYTIC
+ * RAY CASTER over the primitive scene of this build (table plane, pipe capsules r = 1 cm, hole tube, finger-pad boxes);
+ * depth = OpenGL window depth far (z - near) / (z (far - near)), background 1.  RGB is a flat colour per object on the
+ * reference's uint8 scale (envs/peg_in_hole.py:295; its shading cannot be reproduced without TinyRenderer): pipe/hole
+ * 232 (0.91 white, pipe.urdf:26, hole.urdf:14), table 153, fingers 77, background 255. */
+static double ray_sphere(const v3 o, const v3 d, const v3 c, double r) {
+  v3 oc; v_sub(oc, o, c);
+  double b = v_dot(oc, d), cc = v_dot(oc, oc) - r * r, disc = b * b - cc;
+  if (disc < 0) return 1e30;
+  double t = -b - sqrt(disc);
+  return t > 0 ? t : 1e30;
+}
+static double ray_capsule(const v3 o, const v3 d, const v3 a, const v3 b, double r) {   /* d unit */
+  v3 ba, oa; v_sub(ba, b, a); v_sub(oa, o, a);
+  double baba = v_dot(ba, ba), bard = v_dot(ba, d), baoa = v_dot(ba, oa), rdoa = v_dot(d, oa), oaoa = v_dot(oa, oa);
+  double A = baba - bard * bard, B = baba * rdoa - baoa * bard, Cc = baba * oaoa - baoa * baoa - r * r * baba;
+  double h = B * B - A * Cc, best = 1e30;
+  if (h >= 0 && A > 1e-18) {
+    double t = (-B - sqrt(h)) / A, y = baoa + t * bard;
+    if (y > 0 && y < baba && t > 0) best = t;
+  }
+  double t1 = ray_sphere(o, d, a, r), t2 = ray_sphere(o, d, b, r);
+  if (t1 < best) best = t1;
+  if (t2 < best) best = t2;
+  return best;
+}
+static double ray_box(const v3 o, const v3 d, const double* R, const v3 c, const double* hx) {   /* oriented box */
+  v3 oc, ol, dl; v_sub(oc, o, c); m_tmulv(ol, R, oc); m_tmulv(dl, R, d);
+  double tmin = -1e30, tmax = 1e30;
+  for (int k = 0; k < 3; k++) {
+    if (fabs(dl[k]) < 1e-15) { if (fabs(ol[k]) > hx[k]) return 1e30; continue; }
+    double t1 = (-hx[k] - ol[k]) / dl[k], t2 = (hx[k] - ol[k]) / dl[k];
+    if (t1 > t2) { double t = t1; t1 = t2; t2 = t; }
+    if (t1 > tmin) tmin = t1;
+    if (t2 < tmax) tmax = t2;
+  }
+  if (tmin > tmax || tmax <= 0) return 1e30;
+  return tmin > 0 ? tmin : 1e30;      /* eye inside the box: not rendered */
+}
+static double ray_tube(const v3 o, const v3 d) {   /* annular tube, axis x, centre HOLE_POS */
+  v3 oc; v_sub(oc, o, HOLE_POS);
+  const double hl = PIH_HOLE_HALFLEN, ri = PIH_HOLE_RIN, ro = PIH_HOLE_ROUT;
+  double best = 1e30;
+  double a = d[1] * d[1] + d[2] * d[2], b = oc[1] * d[1] + oc[2] * d[2];
+  for (int pass = 0; pass < 2; pass++) {          /* outer surface (entering), inner surface (exiting the bore wall from inside) */
+    double rr = pass == 0 ? ro : ri, cc = oc[1] * oc[1] + oc[2] * oc[2] - rr * rr, disc = b * b - a * cc;
+    if (a < 1e-18 || disc < 0) continue;
+    double t = pass == 0 ? (-b - sqrt(disc)) / a : (-b + sqrt(disc)) / a;
+    double x = oc[0] + t * d[0];
+    if (t > 0 && fabs(x) <= hl && t < best) best = t;
+  }
+  for (int side = 0; side < 2; side++) {          /* annular end caps */
+    if (fabs(d[0]) < 1e-15) continue;
+    double t = ((side ? hl : -hl) - oc[0]) / d[0];
+    if (t <= 0 || t >= best) continue;
+    double y = oc[1] + t * d[1], z = oc[2] + t * d[2], r2 = y * y + z * z;
+    if (r2 >= ri * ri && r2 <= ro * ro) best = t;
+  }
+  return best;
+}
+void piho_render(const piho_handle* h, int W, int H, double* out /* [n,H,W,4] */) {
+  const double nearv = 0.001, farv = 1000.0, tanh2 = tan(0.5 * 60.0 * PI / 180.0);
+  for (int e = 0; e < h->cfg.n_envs; e++) {
+    const double* s = h->env[e].s;
+    LinkKin K[NL];
+    fk(&s[PIHO_S_QARM], &s[PIHO_S_POS], &s[PIHO_S_QUAT], &s[PIHO_S_QJ], 0, NL, K);
+    v3 eye; double eR[9]; ee_pose(K, eye, eR);
+    v3 vtx[25]; int nv = 0;
+    for (int i = 0; i < PIH_PIPE_NSAMP; i++) if (SAMP_VERTEX[i]) {
+      const LinkKin* k = &K[ANL + SAMP_LINK[i]]; v3 loc = {0, SAMP_Y[i], 0};
+      m_mulv(vtx[nv], k->R, loc); v_add(vtx[nv], vtx[nv], k->o); nv++;
+    }
+    v3 fc[2];
+    for (int f = 0; f < 2; f++) { m_mulv(fc[f], K[PIH_FINGER_LINK0 + f].R, FBOX_C[f]); v_add(fc[f], fc[f], K[PIH_FINGER_LINK0 + f].o); }
+    double* img = out + (size_t)e * H * W * 4;
+    for (int i = 0; i < H; i++)
+      for (int j = 0; j < W; j++) {
+        double xc = (2.0 * (j + 0.5) / W - 1.0) * tanh2, yc = (1.0 - 2.0 * (i + 0.5) / H) * tanh2;   /* aspect 1 */
+        v3 d = {xc, yc, -1.0}; double dn = v_norm(d); d[0] /= dn; d[1] /= dn; d[2] /= dn;
+        double best = 1e30, col = 255.0;
+        if (d[2] < 0) { double t = (PIH_TABLE_Z - eye[2]) / d[2]; if (t > 0 && t < best) { best = t; col = 153.0; } }
+        for (int sg = 0; sg < 24; sg++) { double t = ray_capsule(eye, d, vtx[sg], vtx[sg + 1], PIH_PIPE_RADIUS); if (t < best) { best = t; col = 232.0; } }
+        { double t = ray_tube(eye, d); if (t < best) { best = t; col = 232.0; } }
+        for (int f = 0; f < 2; f++) { double t = ray_box(eye, d, K[PIH_FINGER_LINK0 + f].R, fc[f], FBOX_H); if (t < best) { best = t; col = 77.0; } }
+        double depth = 1.0;
+        if (best < 1e29) { double z = best / dn; depth = farv * (z - nearv) / (z * (farv - nearv)); }   /* z = distance along the view axis */
+        double* px = img + ((size_t)i * W + j) * 4;
+        px[0] = depth; px[1] = col; px[2] = col; px[3] = col;
+      }
+  }
+}
+
+/* Grasp-rectangle labels of random_grasp (envs/peg_in_hole.py:72-99): a length 0.1 x width 0.2 rectangle (image-relative)
+ * centred on the image, rotated by `angle`, rasterised with skimage.draw.polygon, which is ABSENT here (parity unpinned):
+ * restated as the even-odd crossing test of scikit-image's point_in_polygon over integer pixel coordinates.  The reference
+ * writes pos_img[cc, rr] with rr = polygon rows built from the x-like coordinates (a[0], ...), i.e. image[c][r].
+ * out [4, S, S] = pos (50 inside), sin(2 ang), cos(2 ang), wid (|a - d| inside). */
+static int pnpoly4(const double* xp, const double* yp, double x, double y) {
+  int c = 0;
+  for (int i = 0, j = 3; i < 4; j = i++)
+    if ((((yp[i] <= y) && (y < yp[j])) || ((yp[j] <= y) && (y < yp[i]))) && (x < (xp[j] - xp[i]) * (y - yp[i]) / (yp[j] - yp[i]) + xp[i])) c = !c;
+  return c;
+}
+void piho_grasp_labels(double angle, int S, double* out, double* meta /* x, y, angle_deg, width, length */) {
+  const double length = 0.1, width = 0.2, ca = cos(angle), sa = sin(angle);
+  double a[2] = {(1. + length * ca + width * sa) / 2 * S, (1. - length * sa + width * ca) / 2 * S};
+  double b[2] = {(1. - length * ca - width * sa) / 2 * S, (1. + length * sa - width * ca) / 2 * S};
+  double cc[2] = {(1. - length * ca + width * sa) / 2 * S, (1. + length * sa + width * ca) / 2 * S};
+  double d[2] = {(1. + length * ca - width * sa) / 2 * S, (1. - length * sa - width * ca) / 2 * S};
+  double rrr[4] = {a[0], cc[0], b[0], d[0]}, ccc[4] = {a[1], cc[1], b[1], d[1]};
+  double wpx = hypot(a[0] - d[0], a[1] - d[1]), lpx = hypot(a[0] - cc[0], a[1] - cc[1]);
+  for (int i = 0; i < S * S; i++) { out[i] = 0; out[S * S + i] = 0; out[2 * S * S + i] = 1; out[3 * S * S + i] = 0; }
+  for (int r = 0; r < S; r++)
+    for (int c = 0; c < S; c++)
+      if (pnpoly4(ccc, rrr, (double)c, (double)r)) {       /* polygon(r = rrr, c = ccc): point_in_polygon(cp, rp, c, r) */
+        size_t idx = (size_t)c * S + r;                    /* img[cc, rr] */
+        out[idx] = 50; out[S * S + idx] = sin(2 * angle); out[2 * S * S + idx] = cos(2 * angle); out[3 * S * S + idx] = wpx;
+      }
+  if (meta) { meta[0] = 0; meta[1] = 0; meta[2] = angle / PI * 180.; meta[3] = wpx; meta[4] = lpx; }
 }
 
 /* ------------------------------------------------------------------------------------------ accessors */

@@ -29,7 +29,7 @@ enum {
   PIHO_S_QARM = 0, PIHO_S_QDARM = 9, PIHO_S_POS = 18, PIHO_S_QUAT = 21, PIHO_S_VLIN = 25, PIHO_S_VANG = 28,
   PIHO_S_QJ = 31, PIHO_S_QDJ = 54, PIHO_S_TARGET = 77,
   PIHO_S_FSM = 86, PIHO_S_FSMT = 87, PIHO_S_DONE = 88, PIHO_S_GRASP = 89, PIHO_S_RANDY = 90, PIHO_S_ATTACH = 91,
-  PIHO_S_RNG = 92, PIHO_S_STEPS = 93, PIHO_S_OFFSET = 94, PIHO_S_SPARE = 97
+  PIHO_S_RNG = 92, PIHO_S_STEPS = 93, PIHO_S_OFFSET = 94, PIHO_S_SPARE = 97, PIHO_S_GRASP_ANGLE = 111
 };
 
 typedef struct {
@@ -66,6 +66,11 @@ void piho_set_state(piho_handle* h, const double* in /* [n,128] */);   /* also c
 void piho_get_tip_pose(const piho_handle* h, double* out /* [n,7] */);
 void piho_get_contact_force(const piho_handle* h, double* out /* [n] sum of normal impulses / dt of the last step */);
 void piho_get_ncontacts(const piho_handle* h, int32_t* out /* [n] */);
+
+/* PegInHole.render (envs/peg_in_hole.py:276-304) as an analytic ray caster: out [n,H,W,4] = depth, r, g, b */
+void piho_render(const piho_handle* h, int W, int H, double* out);
+/* grasp-rectangle label images of random_grasp (envs/peg_in_hole.py:72-99): out [4,S,S] = pos, sin, cos, wid; meta [5] */
+void piho_grasp_labels(double angle, int S, double* out, double* meta);
 
 /* stand-alone primitives (KATs and stage-wise GPU bring-up) */
 void piho_fk_arm(const double q[9], int link /* 0..8, or 9 = EE */, double pos[3], double quat[4]);

@@ -17,7 +17,7 @@ S_FSM, S_FSMT, S_DONE, S_GRASP, S_RANDY, S_ATTACH, S_RNG, S_STEPS, S_OFFSET = 86
 S_TIP, S_CFORCE, S_NCONTACT, S_PGS_ITERS, S_CACHE_N = 98, 105, 106, 107, 128
 
 EXPORTS = ["pih_default_config", "pih_abi_version", "pih_create", "pih_destroy", "pih_reset", "pih_step", "pih_step_n",
-           "pih_get_state", "pih_set_state", "pih_ik", "pih_ik_ur5", "pih_timing", "pih_set_timing", "pih_last_error"]
+           "pih_get_state", "pih_set_state", "pih_ik", "pih_ik_ur5", "pih_render", "pih_grasp_labels", "pih_timing", "pih_set_timing", "pih_last_error"]
 
 
 class PihConfig(C.Structure):
@@ -59,6 +59,8 @@ def load():
     L.pih_set_state.argtypes = [vp, C.c_int, vp, vp]
     L.pih_ik.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.pih_ik_ur5.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.pih_render.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.pih_grasp_labels.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.pih_timing.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.pih_set_timing.argtypes = [vp, C.c_int]
     L.pih_last_error.argtypes = [vp]

@@ -419,6 +419,7 @@ template <class W> PIH_HD void controller(W& w, Shared& sh, const Params& P, con
     // random_grasp loop body, envs/peg_in_hole.py:53-112 (update_state :206-212, grasp_process :122-204)
     int st = (int)S[PIH_S_FSM];
     int nstep = (int)(S[PIH_S_FSMT] * (real)240 + (real)0.5) + 1;      // S[FSMT] holds the state clock in seconds, as the reference does
+    const int st_prev = st;
     if (nstep >= FSM_STEPS[st]) { st += 1; nstep = 0; if (st >= 10) st = 0; }
     S[PIH_S_FSM] = (real)st; S[PIH_S_FSMT] = (real)nstep * (real)(1.0 / 240.0);
     real tip[7]; tip_pose(sh, tip);
@@ -426,6 +427,7 @@ template <class W> PIH_HD void controller(W& w, Shared& sh, const Params& P, con
     V3 rv = mul(q_to_m(tornq), mk(0, S[PIH_S_RANDY], 0));
     V3 tpos = mk(tip[0], tip[1], tip[2]) + rv;
     V3 tp = vel_constraint(eep, tpos, P.dv);
+    if (st == 2 && st_prev != 2) S[PIH_S_GRASP_ANGLE] = (real)atan2(rv.y, rv.x);   // label angle, envs/peg_in_hole.py:72
     real yaw = yaw_from_quat(tornq);
     V3 hole = ld3(HOLE_POS);
     Q4 tq; tq.x = 0; tq.y = 0; tq.z = 0; tq.w = 1;

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "pih_device.h"
+#include "pih_render.h"
 
 using namespace pih;
 
@@ -119,6 +120,48 @@ __global__ void __launch_bounds__(64) pih_ik_ur5_kernel(Params P, const float* _
     float v = 0;
     for (int k = 0; k < 6; k++) v += qs[k] * (lane == k);
     qout[i * 6 + lane] = v;
+  }
+}
+
+// wrist camera (p12): grid = (strips, envs), 256 threads; out float[count, H, W, 4] = depth, r, g, b
+__global__ void __launch_bounds__(RENDER_THREADS) pih_render_kernel(const float* __restrict__ state, float* __restrict__ out,
+                                                                    int env_begin, int W, int H, int rows_per_strip) {
+  __shared__ Shared sh;
+  __shared__ Scene sc;
+  const int tid = threadIdx.x, e = blockIdx.y, env = env_begin + e;
+  const int r0 = blockIdx.x * rows_per_strip, r1 = min(H, r0 + rows_per_strip);
+  Wave w; w.l = tid; w.counter = 0;
+  const float* rec = state + (size_t)env * PIH_STATE_WORDS;
+  for (int i = tid; i < PIH_STATE_WORDS; i += RENDER_THREADS) sh.S[i] = rec[i];
+  __syncthreads();
+  const float T = PIH_CAM_TANH2, sy = 2.0f / H, sx = 2.0f / W;
+  // camera-plane v of the strip's top and bottom pixel edges (row 0 is the top of the image)
+  scene_setup(w, sh, sc, tid, (1.0f - sy * r1) * T, (1.0f - sy * r0) * T);
+  float4* img = reinterpret_cast<float4*>(out) + (size_t)e * H * W;
+  const int p0 = r0 * W, p1 = r1 * W;
+  for (int p = p0 + tid; p < p1; p += RENDER_THREADS) {
+    int i = p / W, j = p - i * W;
+    real4 c = shade(sc, (sx * (j + 0.5f) - 1.0f) * T, (1.0f - sy * (i + 0.5f)) * T);
+    img[p] = make_float4(c.x, c.y, c.z, c.w);
+  }
+}
+
+// label images: grid = (ceil(S*S/256), envs); out[e][k][y][x], image index [cc][rr] of the reference = [x-like c][r]
+__global__ void __launch_bounds__(256) pih_labels_kernel(const float* __restrict__ state, float* __restrict__ out, float* __restrict__ meta,
+                                                         int env_begin, int S) {
+  const int e = blockIdx.y, env = env_begin + e;
+  const float angle = state[(size_t)env * PIH_STATE_WORDS + PIH_S_GRASP_ANGLE];
+  const LabelRect L = label_rect(angle, S);
+  const int idx = blockIdx.x * 256 + threadIdx.x, SS = S * S;
+  if (idx < SS) {
+    const int c = idx / S, r = idx - c * S;              // element [c][r] of the image
+    const bool in = label_inside(L, (float)c, (float)r);
+    float* o = out + (size_t)e * 4 * SS;
+    o[idx] = in ? 50.0f : 0.0f; o[SS + idx] = in ? L.s2 : 0.0f; o[2 * SS + idx] = in ? L.c2 : 1.0f; o[3 * SS + idx] = in ? L.wpx : 0.0f;
+  }
+  if (meta && blockIdx.x == 0 && threadIdx.x == 0) {
+    float* m = meta + (size_t)e * 5;
+    m[0] = 0; m[1] = 0; m[2] = angle * (180.0f / 3.14159265358979f); m[3] = L.wpx; m[4] = L.lpx;
   }
 }
 
@@ -287,6 +330,30 @@ int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, con
 int pih_ik_ur5(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream) {
   if (!h || n <= 0 || !q0_dev || !tpos_dev || !tquat_dev || !qout_dev) return -2;
   hipLaunchKernelGGL(pih_ik_ur5_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, h->P, q0_dev, tpos_dev, tquat_dev, qout_dev);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int pih_render(pih_handle* h, float* out_dev, int width, int height, int env_begin, int env_count, void* stream) {
+  if (!h || !out_dev || width <= 0 || height <= 0 || env_begin < 0 || env_count <= 0 || env_begin + env_count > h->cfg.n_envs) {
+    if (h) h->err = "pih_render: bad arguments";
+    return -2;
+  }
+  if ((reinterpret_cast<uintptr_t>(out_dev) & 15) != 0) { h->err = "pih_render: out_dev must be 16-byte aligned"; return -2; }
+  // strips of ~32 rows: each workgroup amortises one forward-kinematics pass over >= 32 * width pixels
+  int rows = 32, strips = (height + rows - 1) / rows;
+  if (env_count > 65535) { h->err = "pih_render: env_count > 65535 per call"; return -2; }
+  hipLaunchKernelGGL(pih_render_kernel, dim3(strips, env_count), dim3(RENDER_THREADS), 0, (hipStream_t)stream, h->state, out_dev, env_begin, width, height, rows);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int pih_grasp_labels(pih_handle* h, float* out_dev, float* meta_dev, int size, int env_begin, int env_count, void* stream) {
+  if (!h || !out_dev || size <= 0 || env_begin < 0 || env_count <= 0 || env_count > 65535 || env_begin + env_count > h->cfg.n_envs) {
+    if (h) h->err = "pih_grasp_labels: bad arguments";
+    return -2;
+  }
+  hipLaunchKernelGGL(pih_labels_kernel, dim3((size * size + 255) / 256, env_count), dim3(256), 0, (hipStream_t)stream, h->state, out_dev, meta_dev, env_begin, size);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -1,0 +1,221 @@
+// pih_render.h -- the wrist camera of PegInHole.render (envs/peg_in_hole.py:276-304) as an analytic ray caster (p12).
+//
+// Reference camera: eye = world position of link 11 (grasp target), target = eye - (0,0,10), up = (0,1,0), fov 60 deg,
+// aspect 1, near 0.001, far 1000, 300 x 300, result = concat(depth buffer, rgb).  With that target/up the camera basis is
+// world-axis aligned (side = +x, up = +y, forward = -z), so the ray through pixel (i, j) is (xc, yc, -1) in WORLD axes and
+// the eye-space depth of a hit is simply eye.z - hit.z.  The scene is the primitive set the physics uses: table plane,
+// 24 pipe capsules (r = 1 cm), the hole tube, the two finger-pad boxes.  TinyRenderer's shading is not reproduced: RGB is
+// one flat value per object (see oracle/pih_oracle.c piho_render, the checker of this file).
+//
+// Mapping: one 256-thread workgroup per (env, strip of rows).  The workgroup runs the forward kinematics once, lane 0..23
+// projects the capsules and keeps those whose screen-space bound touches the strip (LDS list), then every thread shades
+// pixels of the strip (consecutive threads = consecutive pixels => one coalesced 16-byte store per pixel).
+#pragma once
+#include "pih_device.h"
+
+namespace pih {
+
+constexpr int RENDER_THREADS = 256;
+constexpr int NSEG = 24;
+
+struct Scene {
+  real eye[3];
+  real vtx[NSEG + 1][3];
+  real fR[2][9], fc[2][3];
+  int seg[NSEG]; int nseg;
+  int box_on[2], tube_on;
+};
+
+#define PIH_CAM_NEAR ((real)0.001)
+#define PIH_CAM_FAR ((real)1000)
+#define PIH_CAM_TANH2 ((real)0.57735026918962576451)   // tan(30 deg)
+#define PIH_COL_BG ((real)255)
+#define PIH_COL_TABLE ((real)153)
+#define PIH_COL_PIPE ((real)232)
+#define PIH_COL_FINGER ((real)77)
+
+PIH_HD real ray_sphere(V3 oc, V3 d, real r) {   // oc = eye - centre, d unit
+  real b = dot(oc, d), c = dot(oc, oc) - r * r, disc = b * b - c;
+  real t = -b - (real)sqrt(max_(disc, (real)0));
+  return (disc >= 0 && t > 0) ? t : PIH_BIG;
+}
+PIH_HD real ray_capsule(V3 o, V3 d, V3 a, V3 b, real r) {
+  V3 ba = b - a, oa = o - a;
+  real baba = dot(ba, ba), bard = dot(ba, d), baoa = dot(ba, oa), rdoa = dot(d, oa), oaoa = dot(oa, oa);
+  real A = baba - bard * bard, B = baba * rdoa - baoa * bard, C = baba * oaoa - baoa * baoa - r * r * baba;
+  real h = B * B - A * C, best = PIH_BIG;
+  if (h >= 0 && A > (real)1e-18) {
+    real t = (-B - (real)sqrt(h)) / A, y = baoa + t * bard;
+    if (y > 0 && y < baba && t > 0) best = t;
+  }
+  real t1 = ray_sphere(oa, d, r), t2 = ray_sphere(o - b, d, r);
+  best = t1 < best ? t1 : best;
+  best = t2 < best ? t2 : best;
+  return best;
+}
+PIH_HD real ray_box(V3 o, V3 d, const M3& R, V3 c, V3 hx) {
+  V3 ol = tmul(R, o - c), dl = tmul(R, d);
+  real tmin = -PIH_BIG, tmax = PIH_BIG;
+  const real olv[3] = {ol.x, ol.y, ol.z}, dlv[3] = {dl.x, dl.y, dl.z}, hv[3] = {hx.x, hx.y, hx.z};
+  bool miss = false;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (absr(dlv[k]) < (real)1e-15) { miss = miss || absr(olv[k]) > hv[k]; continue; }
+    real inv = (real)1 / dlv[k], t1 = (-hv[k] - olv[k]) * inv, t2 = (hv[k] - olv[k]) * inv;
+    real lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+    tmin = lo > tmin ? lo : tmin; tmax = hi < tmax ? hi : tmax;
+  }
+  if (miss || tmin > tmax || tmax <= 0) return PIH_BIG;
+  return tmin > 0 ? tmin : PIH_BIG;
+}
+PIH_HD real ray_tube(V3 o, V3 d) {
+  V3 oc = o - ld3(HOLE_POS);
+  const real hl = PIH_HOLE_HALFLEN, ri = PIH_HOLE_RIN, ro = PIH_HOLE_ROUT;
+  real best = PIH_BIG;
+  real a = d.y * d.y + d.z * d.z, b = oc.y * d.y + oc.z * d.z, r2o = oc.y * oc.y + oc.z * oc.z;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    real rr = pass == 0 ? ro : ri, c = r2o - rr * rr, disc = b * b - a * c;
+    if (a < (real)1e-18 || disc < 0) continue;
+    real sq = (real)sqrt(disc), t = (pass == 0 ? -b - sq : -b + sq) / a, x = oc.x + t * d.x;
+    if (t > 0 && absr(x) <= hl && t < best) best = t;
+  }
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    if (absr(d.x) < (real)1e-15) continue;
+    real t = ((side ? hl : -hl) - oc.x) / d.x;
+    if (t <= 0 || t >= best) continue;
+    real y = oc.y + t * d.y, z = oc.z + t * d.z, r2 = y * y + z * z;
+    if (r2 >= ri * ri && r2 <= ro * ro) best = t;
+  }
+  return best;
+}
+
+// conservative screen-space bound (in tan-angle units: u = x / depth, v = y / depth) of a sphere; false = cannot bound
+// (sphere reaches the eye plane), the caller then keeps the primitive for every strip
+PIH_HD bool sphere_bound(V3 rel, real r, real& u0, real& u1, real& v0, real& v1) {
+  real dpt = -rel.z;                      // depth along the view axis
+  if (dpt <= r + (real)1e-4) return false;
+  real u = rel.x / dpt, v = rel.y / dpt;
+  real rho = r * (real)sqrt((real)1 + u * u + v * v) / (dpt - r) * (real)1.5 + (real)1e-4;   // generous
+  u0 = u - rho; u1 = u + rho; v0 = v - rho; v1 = v + rho;
+  return true;
+}
+
+// Scene set-up for one strip [yc_lo, yc_hi] (camera-plane v range of the strip, v grows upwards).  All threads call it.
+template <class W> PIH_HD void scene_setup(W& w, Shared& sh, Scene& sc, int tid, real v_lo, real v_hi) {
+  fk_all(w, sh);
+  w.sync();
+  if (tid == 0) {
+    V3 p; M3 R; ee_pose(sh, p, R); st3(sc.eye, p);
+    sc.nseg = 0;
+  }
+  if (tid < NSAMP && SAMP_VERTEX[tid]) {
+    int k = 0;
+    for (int i = 0; i < tid; i++) k += SAMP_VERTEX[i];
+    int L = ANL + SAMP_LINK[tid];
+    st3(sc.vtx[k], ld3(sh.LO[L]) + mul(ldm(sh.a.LR[L]), mk(0, SAMP_Y[tid], 0)));
+  }
+  if (tid < 2) {
+    int L = PIH_FINGER_LINK0 + tid;
+    M3 R = ldm(sh.a.LR[L]);
+    stm(sc.fR[tid], R); st3(sc.fc[tid], ld3(sh.LO[L]) + mul(R, ld3(FBOX_C[tid])));
+  }
+  w.sync();
+  const V3 eye = ld3(sc.eye);
+  const real T = PIH_CAM_TANH2;
+  if (tid < NSEG) {
+    real a0, a1, b0, b1, c0, c1, d0, d1;
+    bool ok = sphere_bound(ld3(sc.vtx[tid]) - eye, PIH_PIPE_RADIUS, a0, a1, b0, b1) &&
+              sphere_bound(ld3(sc.vtx[tid + 1]) - eye, PIH_PIPE_RADIUS, c0, c1, d0, d1);
+    bool on = true;
+    if (ok) {
+      real u0 = a0 < c0 ? a0 : c0, u1 = a1 > c1 ? a1 : c1, v0 = b0 < d0 ? b0 : d0, v1 = b1 > d1 ? b1 : d1;
+      on = !(u1 < -T || u0 > T || v1 < v_lo || v0 > v_hi);
+    }
+#ifdef PIH_HOST_EMUL
+    if (on) sc.seg[sc.nseg++] = tid;
+#else
+    if (on) sc.seg[atomicAdd(&sc.nseg, 1)] = tid;
+#endif
+  }
+  if (tid >= 32 && tid < 34) {            // finger boxes: bounding sphere of the box
+    int f = tid - 32;
+    V3 h = ld3(FBOX_H);
+    real a0, a1, b0, b1;
+    bool ok = sphere_bound(ld3(sc.fc[f]) - eye, norm(h), a0, a1, b0, b1);
+    sc.box_on[f] = !ok || !(a1 < -T || a0 > T || b1 < v_lo || b0 > v_hi);
+  }
+  if (tid == 34) {                        // hole tube: bounding sphere
+    real a0, a1, b0, b1;
+    real rad = (real)sqrt(PIH_HOLE_HALFLEN * PIH_HOLE_HALFLEN + PIH_HOLE_ROUT * PIH_HOLE_ROUT);
+    bool ok = sphere_bound(ld3(HOLE_POS) - eye, rad, a0, a1, b0, b1);
+    sc.tube_on = !ok || !(a1 < -T || a0 > T || b1 < v_lo || b0 > v_hi);
+  }
+  w.sync();
+}
+
+// one pixel: xc, yc = camera-plane coordinates of the pixel centre (already multiplied by tan(fov/2))
+PIH_HD real4 shade(const Scene& sc, real xc, real yc) {
+  const V3 eye = ld3(sc.eye);
+  real inv = rsqrt_((real)1 + xc * xc + yc * yc);
+  V3 d = mk(xc * inv, yc * inv, -inv);
+  real best = PIH_BIG, col = PIH_COL_BG;
+  {
+    real t = (PIH_TABLE_Z - eye.z) / d.z;
+    if (t > 0) { best = t; col = PIH_COL_TABLE; }
+  }
+  const int ns = sc.nseg;
+  for (int k = 0; k < ns; k++) {
+    int s = sc.seg[k];
+    real t = ray_capsule(eye, d, ld3(sc.vtx[s]), ld3(sc.vtx[s + 1]), PIH_PIPE_RADIUS);
+    if (t < best) { best = t; col = PIH_COL_PIPE; }
+  }
+  if (sc.tube_on) {
+    real t = ray_tube(eye, d);
+    if (t < best) { best = t; col = PIH_COL_PIPE; }
+  }
+  for (int f = 0; f < 2; f++)
+    if (sc.box_on[f]) {
+      real t = ray_box(eye, d, ldm(sc.fR[f]), ld3(sc.fc[f]), ld3(FBOX_H));
+      if (t < best) { best = t; col = PIH_COL_FINGER; }
+    }
+  real depth = 1;
+  if (best < (real)1e29) {
+    real z = best * inv;                 // eye-space depth = t * (-d.z)
+    depth = PIH_CAM_FAR * (z - PIH_CAM_NEAR) / (z * (PIH_CAM_FAR - PIH_CAM_NEAR));
+  }
+  real4 o; o.x = depth; o.y = col; o.z = col; o.w = col;
+  return o;
+}
+
+// ---- grasp-rectangle labels (envs/peg_in_hole.py:72-99): see oracle/pih_oracle.c piho_grasp_labels
+struct LabelRect { real rrr[4], ccc[4], s2, c2, wpx, lpx; };
+PIH_HD LabelRect label_rect(real angle, int S) {
+  const real length = (real)0.1, width = (real)0.2;
+  real sa, ca; sincos_(angle, &sa, &ca);
+  const real h = (real)0.5 * (real)S;
+  LabelRect L;
+  // vertex order a, c, b, d of the reference
+  L.rrr[0] = ((real)1 + length * ca + width * sa) * h; L.ccc[0] = ((real)1 - length * sa + width * ca) * h;
+  L.rrr[1] = ((real)1 - length * ca + width * sa) * h; L.ccc[1] = ((real)1 + length * sa + width * ca) * h;
+  L.rrr[2] = ((real)1 - length * ca - width * sa) * h; L.ccc[2] = ((real)1 + length * sa - width * ca) * h;
+  L.rrr[3] = ((real)1 + length * ca - width * sa) * h; L.ccc[3] = ((real)1 - length * sa - width * ca) * h;
+  real dx = L.rrr[0] - L.rrr[3], dy = L.ccc[0] - L.ccc[3]; L.wpx = (real)sqrt(dx * dx + dy * dy);
+  dx = L.rrr[0] - L.rrr[1]; dy = L.ccc[0] - L.ccc[1]; L.lpx = (real)sqrt(dx * dx + dy * dy);
+  sincos_((real)2 * angle, &L.s2, &L.c2);
+  return L;
+}
+PIH_HD bool label_inside(const LabelRect& L, real x /* c */, real y /* r */) {   // xp = ccc, yp = rrr
+  bool in = false;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int j = (i + 3) & 3;
+    real yi = L.rrr[i], yj = L.rrr[j], xi = L.ccc[i], xj = L.ccc[j];
+    bool span = ((yi <= y) && (y < yj)) || ((yj <= y) && (y < yi));
+    if (span && (x < (xj - xi) * (y - yi) / (yj - yi) + xi)) in = !in;
+  }
+  return in;
+}
+
+}  // namespace pih

@@ -10,6 +10,8 @@ TASK_LIST = {
 }
 
 _MODES = {'action': 0, 'scripted': 1}
+GRASP_IMG_STEP = 540       # physics steps before the state machine enters state 2 (60 + 480, envs/peg_in_hole.py:206-212,263)
+IMG_SHAPE = (300, 300)     # input_rgb_shape[:2] / output_shape, envs/peg_in_hole.py:270-272
 
 
 def _default_backend(n, offsets, **cfg):
@@ -21,6 +23,24 @@ def _to_numpy(x):
     if hasattr(x, "detach"):
         x = x.detach().cpu().numpy()
     return np.asarray(x)
+
+
+def scripted_episode(backend, actions, n):
+    """One reference step() in scripted mode = one whole random_grasp episode (envs/peg_in_hole.py:33-37,53-116): 2226
+    physics steps.  get_info returns observation = the wrist-camera image taken when the state machine enters state 2
+    (after exactly GRASP_IMG_STEP physics steps, :65-67), reward = q, done, info = [[pos, sin, cos, wid label images],
+    [x, y, angle_deg, width, length]] (:116).  Returns (images [n,300,300,4], reward [n], done [n], infos)."""
+    backend.step_n(GRASP_IMG_STEP, actions)
+    img = _to_numpy(backend.render(IMG_SHAPE[1], IMG_SHAPE[0])).astype(np.float64)
+    rew = done = None
+    for _ in range(8):
+        _, rew, done = backend.step_n(320, actions)
+        if bool(_to_numpy(done).all()):
+            break
+    lab, meta = backend.grasp_labels(IMG_SHAPE[0])
+    lab, meta = _to_numpy(lab), _to_numpy(meta)
+    infos = [[[lab[i, 0], lab[i, 1], lab[i, 2], lab[i, 3]], [float(v) for v in meta[i]]] for i in range(n)]
+    return img, _to_numpy(rew), _to_numpy(done), infos
 
 
 class BaseEnv(object):
@@ -71,11 +91,15 @@ class BaseEnv(object):
                 self.observations[i] = obs[i]
                 self.rewards[i] = float(rew[i])
                 self.dones[i] = bool(done[i])
-                self.infos[i] = {}
+                self.infos[i] = self._scripted_infos[i] if self.mode == 'scripted' else {}
         return self.observations, self.rewards, self.dones, self.infos
 
     def render(self, mode='rgb_array'):
-        return None                     # EE camera path is out of scope
+        """envs/base_env.py:79-81 calls every agent's render and returns None; the images (PegInHole.render,
+        envs/peg_in_hole.py:276-304) are kept in `self.images` ([task_num] arrays of [300,300,4] = depth, r, g, b)."""
+        img = _to_numpy(self._backend.render(IMG_SHAPE[1], IMG_SHAPE[0])).astype(np.float64)
+        self.images = [img[i] for i in range(self.task_num)]
+        return None
 
     def close(self):
         if hasattr(self._backend, "close"):
@@ -93,12 +117,8 @@ class BaseEnv(object):
 
     def _step_backend(self, a):
         if self.mode == 'scripted':
-            # one reference step() = one whole scripted episode (envs/peg_in_hole.py:33-37,53-112): 2226 physics steps
-            obs = rew = done = None
-            for _ in range(8):
-                obs, rew, done = self._backend.step_n(320, self._wrap_actions(a))
-                if bool(_to_numpy(done).all()):
-                    break
+            img, rew, done, self._scripted_infos = scripted_episode(self._backend, self._wrap_actions(a), self.task_num)
+            return img, rew, done
         else:
             obs, rew, done = self._backend.step(self._wrap_actions(a))
         return _to_numpy(obs).astype(np.float32), _to_numpy(rew), _to_numpy(done)

@@ -3,7 +3,7 @@ nesting (envs/base_env_mp.py:7-87).  The reference forks mp_num processes and pi
 Queue(1) pairs; here every agent is one wavefront of ONE batched launch, so there are no worker processes at all."""
 import numpy as np
 
-from .base_env import TASK_LIST, _MODES, _default_backend, _to_numpy
+from .base_env import IMG_SHAPE, TASK_LIST, _MODES, _default_backend, _to_numpy, scripted_episode
 from .utils import (MultiAgentActionSpace, MultiAgentObservationSpace, MPMultiAgentActionSpace,
                     MPMultiAgentObservationSpace, env_offsets)
 
@@ -67,15 +67,12 @@ class BaseEnvMp(object):
                 wrap = torch.as_tensor(a, device=be.device)
         except ImportError:  # pragma: no cover
             pass
+        infos = None
         if self.mode == 'scripted':
-            obs = rew = done = None
-            for _ in range(8):
-                obs, rew, done = be.step_n(320, wrap)
-                if bool(_to_numpy(done).all()):
-                    break
+            obs, rew, done, infos = scripted_episode(be, wrap, self.n)
         else:
             obs, rew, done = be.step(wrap)
-        obs = _to_numpy(obs).astype(np.float32); rew = _to_numpy(rew); done = _to_numpy(done)
+            obs = _to_numpy(obs).astype(np.float32); rew = _to_numpy(rew); done = _to_numpy(done)
         for i in range(self.mp_num):
             if all(self.dones[i]):          # finished workers are skipped (envs/base_env_mp.py:42,45)
                 continue
@@ -85,7 +82,7 @@ class BaseEnvMp(object):
                     self.observations[i][j] = obs[k]
                     self.rewards[i][j] = float(rew[k])
                     self.dones[i][j] = bool(done[k])
-                    self.infos[i][j] = {}
+                    self.infos[i][j] = infos[k] if infos is not None else {}
         return self.observations, self.rewards, self.dones, self.infos
 
     # zero-copy fast path (the nested-list API above wraps it)
@@ -94,6 +91,10 @@ class BaseEnvMp(object):
         return self._backend.step(actions)
 
     def render(self, mode='rgb_array'):
+        """envs/base_env_mp.py:66,85 forwards RENDER to every worker and returns None; the images are kept in
+        `self.images` ([mp_num][sub_num] arrays of [300,300,4] = depth, r, g, b)."""
+        img = _to_numpy(self._backend.render(IMG_SHAPE[1], IMG_SHAPE[0])).astype(np.float64)
+        self.images = self._nest([img[i] for i in range(self.n)])
         return None
 
     def close(self):

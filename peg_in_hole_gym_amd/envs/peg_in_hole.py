@@ -23,7 +23,7 @@ class MetaEnv(object):
         raise NotImplementedError("runs inside pih_reset on the GPU")
 
     def render(self, mode="rgb_array"):
-        raise NotImplementedError("camera path is out of scope (SURVEY.md 8f-3)")
+        raise NotImplementedError("runs inside pih_render on the GPU (BaseEnv.render / PihVecEnv.render)")
 
 
 class PegInHole(MetaEnv):

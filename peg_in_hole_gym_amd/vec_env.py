@@ -128,6 +128,26 @@ class PihVecEnv:
             self._chk(self.L.pih_ik_ur5(self.h, n, q0.data_ptr(), tpos.data_ptr(), tquat.data_ptr(), out.data_ptr(), self._stream()), "pih_ik_ur5")
         return out
 
+    def render(self, width=300, height=300, env_begin=0, env_count=None, out=None):
+        """PegInHole.render (envs/peg_in_hole.py:276-304) for a block of envs: float32 [count, height, width, 4] =
+        (depth buffer, r, g, b) from the wrist camera at the current state (analytic ray caster, flat colours)."""
+        count = self.n - env_begin if env_count is None else env_count
+        if out is None:
+            out = torch.empty(count, height, width, 4, device=self.device)
+        with torch.cuda.device(self.device):
+            self._chk(self.L.pih_render(self.h, out.data_ptr(), width, height, env_begin, count, self._stream()), "pih_render")
+        return out
+
+    def grasp_labels(self, size=300, env_begin=0, env_count=None):
+        """Label images + [x, y, angle_deg, width, length] of random_grasp (envs/peg_in_hole.py:72-99,116):
+        (float32 [count, 4, size, size] = pos, sin, cos, wid ; float32 [count, 5])."""
+        count = self.n - env_begin if env_count is None else env_count
+        out = torch.empty(count, 4, size, size, device=self.device)
+        meta = torch.empty(count, 5, device=self.device)
+        with torch.cuda.device(self.device):
+            self._chk(self.L.pih_grasp_labels(self.h, out.data_ptr(), meta.data_ptr(), size, env_begin, count, self._stream()), "pih_grasp_labels")
+        return out, meta
+
     def set_timing(self, enable):
         self.L.pih_set_timing(self.h, int(enable))
 

@@ -45,6 +45,14 @@ class OracleBackend:
     def contact_force(self):
         return self.o.contact_force()
 
+    def render(self, width=300, height=300):
+        return self.o.render(width, height)
+
+    def grasp_labels(self, size=300):
+        ang = self.o.get_state()[:, 111]
+        outs = [O.grasp_labels(a, size) for a in ang]
+        return np.stack([x[0] for x in outs]), np.stack([x[1] for x in outs])
+
     def close(self):
         pass
 

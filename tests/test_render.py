@@ -1,0 +1,112 @@
+"""Wrist camera (p12): oracle known answers (CPU) and HIP-vs-oracle parity (GPU).
+
+The reference renders with PyBullet's TinyRenderer, absent here: camera model and depth convention are pinned by closed
+forms (OpenGL projection of envs/peg_in_hole.py:276-293), the geometry is the primitive scene of this build, RGB is a flat
+value per object ("parity unpinned" against TinyRenderer's shading)."""
+import numpy as np
+import pytest
+
+NEAR, FAR = 0.001, 1000.0
+TABLE_Z = -0.05
+
+
+def gl_depth(z):
+    return FAR * (z - NEAR) / (z * (FAR - NEAR))
+
+
+def test_depth_of_bare_table_is_the_closed_form(oracle_mod):
+    O = oracle_mod
+    o = O.Oracle(1, mode=1, dv=0.05)
+    for _ in range(540):                          # gripper hovering above the grasp point, pointing straight down
+        o.step(np.zeros((1, 4)))
+    s = o.get_state()
+    s[0, 18] = 5.0                                # move the pipe out of view
+    o.set_state(s)
+    ee = O.fk_arm(s[0, 0:9], 9)[0]
+    img = o.render(40, 30)[0]
+    assert img.shape == (30, 40, 4)
+    # a plane perpendicular to the view axis has ONE depth-buffer value: gl_depth(eye.z - table.z); the finger pads sit
+    # beside the eye, outside the 60 degree cone
+    assert np.allclose(img[:, :, 0], gl_depth(ee[2] - TABLE_Z), atol=1e-12)
+    assert (img[:, :, 1:] == 153.0).all()
+    # at the rest pose the hand is tilted and a finger pad covers part of the straight-down view
+    o2 = O.Oracle(1)
+    assert set(np.unique(o2.render(40, 30)[0][:, :, 1])) >= {153.0, 77.0}
+
+
+def test_pipe_silhouette_and_depth_bounds(oracle_mod):
+    O = oracle_mod
+    o = O.Oracle(2, mode=1, dv=0.05)
+    for _ in range(540):
+        o.step(np.zeros((2, 4)))
+    s = o.get_state()
+    img = o.render(120, 120)
+    for e in range(2):
+        ee = O.fk_arm(s[e, 0:9], 9)[0]
+        pipe = img[e, :, :, 1] == 232.0
+        assert pipe.sum() > 200                                   # the hovering gripper looks down at the pipe
+        z = NEAR * FAR / (FAR - img[e, :, :, 0] * (FAR - NEAR))   # linearised eye depth
+        # pipe pixels are nearer than the table and no nearer than the top of the highest possible sphere
+        assert (z[pipe] < ee[2] - TABLE_Z).all()
+        assert z[pipe].min() > ee[2] - TABLE_Z - 0.5
+        tab = img[e, :, :, 1] == 153.0
+        assert np.allclose(z[tab], ee[2] - TABLE_Z, atol=1e-9)
+        # pipe pixels next to table pixels are silhouette rays: they graze a capsule between its axis height and the table
+        assert ((ee[2] - TABLE_Z) - z[pipe]).min() > 0 and ((ee[2] - TABLE_Z) - z[pipe]).max() < 0.5
+
+
+def test_grasp_labels_geometry(oracle_mod):
+    O = oracle_mod
+    for ang in (0.0, 0.3, -2.1, np.pi / 2):
+        lab, meta = O.grasp_labels(ang, 300)
+        inside = lab[0] == 50
+        assert abs(inside.sum() - 1800) <= 70                      # 0.2*300 x 0.1*300 px
+        assert np.allclose(meta, [0, 0, np.degrees(ang), 60.0, 30.0])
+        cc, rr = np.nonzero(inside)                                # image[cc, rr]
+        assert abs(cc.mean() - 150) < 1.0 and abs(rr.mean() - 150) < 1.0
+        # principal axis of the rectangle: the long (width 0.2) side runs along (sin a, cos a) in (rr, cc) coordinates
+        pts = np.stack([rr - rr.mean(), cc - cc.mean()], 1)
+        w, v = np.linalg.eigh(pts.T @ pts)
+        major = v[:, 1]
+        assert abs(abs(major @ np.array([np.sin(ang), np.cos(ang)])) - 1) < 2e-3
+        assert np.allclose(lab[1][inside], np.sin(2 * ang)) and np.allclose(lab[2][~inside], 1.0)
+
+
+@pytest.mark.gpu
+def test_hip_render_matches_oracle():
+    import torch
+    from oracle import oracle as O
+    from peg_in_hole_gym_amd.vec_env import PihVecEnv
+    n = 6
+    g = PihVecEnv(n, mode=1, dv=0.05, seed=4)
+    g.step_n(540)
+    st = g.state().cpu().numpy()
+    o = O.Oracle(n, mode=1, dv=0.05, seed=4)
+    o.set_state(st[:, :128].astype(np.float64))
+    for (W, H) in ((300, 300), (97, 61)):
+        a = g.render(W, H).cpu().numpy()
+        b = o.render(W, H)
+        assert a.shape == (n, H, W, 4)
+        same = a[..., 1] == b[..., 1]
+        assert same.mean() > 0.997                                  # silhouette pixels may flip class in fp32
+        assert np.array_equal(a[..., 1], a[..., 2]) and np.array_equal(a[..., 1], a[..., 3])
+        assert np.abs(a[..., 0] - b[..., 0])[same].max() < 2e-6     # fp32 depth-buffer value
+        za = NEAR * FAR / (FAR - a[..., 0].astype(np.float64) * (FAR - NEAR)); zb = NEAR * FAR / (FAR - b[..., 0] * (FAR - NEAR))
+        assert np.percentile(np.abs(za - zb)[same], 99) < 2e-4      # metres (fp32 resolution of 1 - near/z at z ~ 0.3 m)
+        assert (a[..., 1] == 232.0).any()
+    # a sub-range of envs renders the same pixels
+    part = g.render(97, 61, env_begin=2, env_count=3).cpu().numpy()
+    assert np.array_equal(part, g.render(97, 61).cpu().numpy()[2:5])
+    # labels from the angle recorded at state-2 entry
+    g.step_n(1)
+    lab, meta = g.grasp_labels(300)
+    lab = lab.cpu().numpy(); meta = meta.cpu().numpy()
+    ang = g.state()[:, 111].cpu().numpy().astype(np.float64)
+    assert (ang != 0).all()
+    for e in range(n):
+        lo, mo = O.grasp_labels(ang[e], 300)
+        assert (lab[e, 0] != lo[0]).sum() <= 40                      # edge pixels: fp32 vs fp64 crossing test
+        agree = lab[e, 0] == lo[0]
+        for k in (1, 2, 3):
+            assert np.abs(lab[e, k] - lo[k])[agree].max() < 1e-4
+        assert np.allclose(meta[e], mo, atol=2e-3)

@@ -95,3 +95,34 @@ def test_facade_scripted_step_runs_a_whole_episode():
     st = env._backend.state()
     assert (st[:, 86] == 9).all() and (st[:, 93] == 2226).all()
     assert all(r[0] in (0.0, 1.0) for r in rew)
+
+
+def test_facade_scripted_step_returns_camera_image_and_labels(oracle_mod):
+    """get_info in scripted mode (envs/peg_in_hole.py:33-37,116): observation = grasp image [300,300,4], info = [[pos, sin,
+    cos, wid], [x, y, angle_deg, width, length]]."""
+    from peg_in_hole_gym_amd.envs import BaseEnv
+    env = BaseEnv(client=None, task="peg-in-hole", task_num=1, mode="scripted", backend_factory=factory)
+    env.reset()
+    obs, rew, done, info = env.step(env.action_space.sample())
+    img = obs[0]
+    assert img.shape == (300, 300, 4) and done == [True]
+    d = img[:, :, 0]
+    assert 0.98 < d.min() <= d.max() <= 1.0
+    assert set(np.unique(img[:, :, 1])) <= {77.0, 153.0, 232.0, 255.0} and 232.0 in img[:, :, 1]     # the pipe is in view
+    (pos, sn, cs, wid), (x, y, ang, width, length) = info[0]
+    assert pos.shape == (300, 300) and set(np.unique(pos)) == {0.0, 50.0}
+    assert x == 0.0 and y == 0.0 and abs(width - 60.0) < 1e-9 and abs(length - 30.0) < 1e-9           # 0.2 * 300, 0.1 * 300
+    a = np.deg2rad(ang)
+    inside = pos > 0
+    assert abs(inside.sum() - 1800) <= 60                                                               # 60 x 30 px rectangle
+    assert np.allclose(sn[inside], np.sin(2 * a)) and np.allclose(cs[inside], np.cos(2 * a)) and np.allclose(cs[~inside], 1.0)
+    assert np.allclose(wid[inside], 60.0) and (wid[~inside] == 0).all()
+    # the recorded angle is the one of the rotated grasp offset at the image instant (:58-59,72)
+    o = oracle_mod.Oracle(1, mode=1, dv=0.05)
+    o.reset()                                  # env.reset() above re-draws the scene the same way
+    for _ in range(540):
+        o.step(np.zeros((1, 4)))
+    tip = o.tip_pose()[0]
+    rv = oracle_mod.rotate_vector([0, o.get_state()[0, 90], 0], tip[3:7])
+    assert abs(np.arctan2(rv[1], rv[0]) - a) < 1e-9
+    assert np.array_equal(o.render(300, 300)[0], img)
