@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIH_ABI_VERSION 1
+#define PIH_ABI_VERSION 2
 #define PIH_STATE_WORDS 256   /* float words per env record: [0,128) physical state, [128,256) warm-start contact cache */
 #define PIH_ACTION_DIM 4      /* envs/peg_in_hole.py:12 */
 #define PIH_OBS_DIM 5         /* envs/peg_in_hole.py:13: finger1, finger2, ee x, y, z */
@@ -70,6 +70,7 @@ typedef struct pih_config {
   int32_t enable_self_collision;
   int32_t debug;              /* 1: fill the debug buffer each step */
   int32_t schedule;           /* 1 (default): longest-job-first dispatch order from the previous step's contact counts; 0: block i = env i */
+  int32_t enable_arm_collision; /* 1 (default): arm collision spheres (pih_model.h PIH_ARM_SPH_*) vs the table plane */
   uint64_t seed;
   float dt;                   /* 1/240 */
   float residual_threshold;   /* 1e-7 */

@@ -17,7 +17,7 @@ NDOF = 38
 class Config(C.Structure):
     _fields_ = [("n_envs", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32), ("ik_iters", C.c_int32),
                 ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("enable_self_collision", C.c_int32),
-                ("env_index0", C.c_int32), ("seed", C.c_uint64), ("dt", C.c_double), ("residual_threshold", C.c_double),
+                ("env_index0", C.c_int32), ("enable_arm_collision", C.c_int32), ("seed", C.c_uint64), ("dt", C.c_double), ("residual_threshold", C.c_double),
                 ("erp", C.c_double), ("warmstart", C.c_double), ("contact_margin", C.c_double), ("linear_slop", C.c_double),
                 ("ik_damping", C.c_double), ("ik_residual", C.c_double), ("dv", C.c_double)]
 

@@ -51,6 +51,9 @@ static const double EE_T[3] = PIH_EE_T;
 static const double ARM_REST[9] = PIH_ARM_REST;
 static const double FBOX_C[2][3] = PIH_FINGER_BOX_C;
 static const double FBOX_H[3] = PIH_FINGER_BOX_H;
+static const int ASPH_LINK[PIH_ARM_NSPH] = PIH_ARM_SPH_LINK;
+static const double ASPH_C[PIH_ARM_NSPH][3] = PIH_ARM_SPH_C;
+static const double ASPH_R[PIH_ARM_NSPH] = PIH_ARM_SPH_R;
 static const int SAMP_LINK[PIH_PIPE_NSAMP] = PIH_PIPE_SAMP_LINK;
 static const double SAMP_Y[PIH_PIPE_NSAMP] = PIH_PIPE_SAMP_Y;
 static const int SAMP_VERTEX[PIH_PIPE_NSAMP] = PIH_PIPE_SAMP_VERTEX;
@@ -464,7 +467,7 @@ struct piho_handle { piho_config cfg; Env* env; void* rows_ws[MAXTHREADS]; };
 void piho_default_config(piho_config* c) {
   memset(c, 0, sizeof *c);
   c->n_envs = 1; c->mode = 0; c->solver_iters = 50; c->ik_iters = 20; c->max_episode_steps = 2227; c->auto_reset = 0;
-  c->enable_self_collision = 1; c->seed = 0; c->dt = 1.0 / 240.0; c->residual_threshold = 1e-7; c->erp = 0.2;
+  c->enable_self_collision = 1; c->enable_arm_collision = 1; c->seed = 0; c->dt = 1.0 / 240.0; c->residual_threshold = 1e-7; c->erp = 0.2;
   c->warmstart = 0.85; c->contact_margin = 0.005; c->linear_slop = 1e-5; c->ik_damping = 0.5; c->ik_residual = 1e-4;
   c->dv = 2.0 / 240.0;
 }
@@ -627,6 +630,17 @@ static void collide(const piho_config* c, Env* E, const LinkKin* K) {
     v_add(p, a1, ee); v_set(p, 0.5 * p[0], 0.5 * p[1], 0.5 * p[2]);
     nca += add_contact(E, g == 0 ? ANL : NL - 1, PIH_EE_PARENT, 2000, p, n, dist, -1.0);
   }
+  /* arm collision spheres vs the table plane (linkA = arm link, linkB = world; keys 3000+): they count against the
+   * arm-contact cap and come before the finger contacts, so a finger-vs-pipe contact is what gets dropped first */
+  if (c->enable_arm_collision)
+    for (int i = 0; i < PIH_ARM_NSPH; i++) {
+      const LinkKin* k = &K[ASPH_LINK[i]];
+      v3 cw; m_mulv(cw, k->R, ASPH_C[i]); v_add(cw, cw, k->o);
+      double depth = cw[2] - PIH_TABLE_Z - ASPH_R[i];
+      if (depth >= margin || nca >= PIHO_CAMAX) continue;
+      v3 n = {0, 0, 1}, p = {cw[0], cw[1], cw[2] - ASPH_R[i] - 0.5 * depth};
+      nca += add_contact(E, ASPH_LINK[i], -1, 3000 + i, p, n, depth, L_MU[ASPH_LINK[i]] * PIH_TABLE_MU);
+    }
   /* finger pad boxes; at most PIHO_CAMAX contacts may involve the arm */
   for (int f = 0; f < 2; f++) {
     const LinkKin* kf = &K[PIH_FINGER_LINK0 + f];

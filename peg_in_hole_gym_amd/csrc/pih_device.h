@@ -56,6 +56,9 @@ PIH_CONST real EE_T[3] = PIH_EE_T;
 PIH_CONST real ARM_REST[9] = PIH_ARM_REST;
 PIH_CONST real FBOX_C[2][3] = PIH_FINGER_BOX_C;
 PIH_CONST real FBOX_H[3] = PIH_FINGER_BOX_H;
+PIH_CONST int ASPH_LINK[PIH_ARM_NSPH] = PIH_ARM_SPH_LINK;
+PIH_CONST real ASPH_C[PIH_ARM_NSPH][3] = PIH_ARM_SPH_C;
+PIH_CONST real ASPH_R[PIH_ARM_NSPH] = PIH_ARM_SPH_R;
 PIH_CONST int SAMP_LINK[NSAMP] = PIH_PIPE_SAMP_LINK;
 PIH_CONST real SAMP_Y[NSAMP] = PIH_PIPE_SAMP_Y;
 PIH_CONST int SAMP_VERTEX[NSAMP] = PIH_PIPE_SAMP_VERTEX;
@@ -90,7 +93,7 @@ typedef real areal;
 
 struct Params {
   real dt, resid, erp, warm, margin, slop, ikdamp, ikres, dv;
-  int iters, ikiters, mode, maxsteps, autoreset, selfcol, debug, env0;
+  int iters, ikiters, mode, maxsteps, autoreset, selfcol, armcol, debug, env0;
   uint64_t seed;
 };
 
@@ -532,6 +535,26 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
     });
     nca += w.alloc_count() - before;
   }
+  // arm collision spheres vs the table plane (linkA = arm link, linkB = world; keys 3000+): they count against the
+  // arm-contact cap and come before the finger contacts, so a finger-vs-pipe contact is what gets dropped first
+  if (P.armcol) {
+    const int before = w.alloc_count();
+    const int allowed = CAMAX - nca;
+    w.par_all(PIH_ARM_NSPH, [&](int i, bool in) {
+      bool valid = false; V3 cw = mk(0, 0, 0); real depth = 0, rs = 0; int L = 0;
+      if (in) {
+        L = ASPH_LINK[i]; rs = ASPH_R[i];
+        cw = ld3(sh.LO[L]) + mul(ldm(sh.a.LR[L]), ld3(ASPH_C[i]));
+        depth = cw.z - (real)PIH_TABLE_Z - rs;
+        valid = depth < margin;
+      }
+      int slot = w.alloc(valid);
+      if (valid && slot < CMAX && (slot - before) < allowed) emit(slot, L, -1, 3000 + i, mk(cw.x, cw.y, cw.z - rs - (real)0.5 * depth), mk(0, 0, 1), depth, L_MU[L] * (real)PIH_TABLE_MU);
+    });
+    int used = w.alloc_count() - before;
+    if (used > allowed) { used = allowed; w.alloc_reset(before + allowed); }
+    nca += used;
+  }
   // finger pad boxes (arm links 7, 8)
   for (int f = 0; f < 2; f++) {
     const int LF = PIH_FINGER_LINK0 + f;
@@ -890,7 +913,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
   // arm-row slots of arm-involving contacts, in contact order (wave-uniform scan; nc <= 48)
   {
     int na = 0;
-    for (int c = 0; c < sh.nc; c++) { int lb = sh.c_lb[c]; bool isarm = lb >= 0 && lb < ANL; sh.c_arow[c] = isarm ? na : -1; na += isarm ? 1 : 0; }
+    for (int c = 0; c < sh.nc; c++) { int la = sh.c_la[c], lb = sh.c_lb[c]; bool isarm = (lb >= 0 && lb < ANL) || la < ANL; sh.c_arow[c] = isarm ? na : -1; na += isarm ? 1 : 0; }
   }
   // motor rows (lane = motor): response of a unit joint impulse; limit rows share W and 1/(J W)
   w.par(NMOT, [&](int m) {
@@ -933,6 +956,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
     int ar = sh.c_arow[c];
     RowOut o; o.wp = wp_row(sh, ov, row); o.wa = ar >= 0 ? sh.b.Wa[3 * ar + k] : nullptr;
     V3 dvp;
+    if (la < ANL && lb < ANL) { for (int j = 0; j < 29; j++) o.wp[j] = 0; }   // arm-vs-world contact: no pipe response
     real jw = response(sh, la, lb, p, dir, -1, o, &dvp);
     real di = (real)1 / jw;
     V3 vr = point_vel(sh, la, p);

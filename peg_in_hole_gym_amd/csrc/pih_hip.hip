@@ -202,7 +202,7 @@ static Params make_params(const pih_config* c) {
   P.dt = c->dt; P.resid = c->residual_threshold; P.erp = c->erp; P.warm = c->warmstart; P.margin = c->contact_margin;
   P.slop = c->linear_slop; P.ikdamp = c->ik_damping; P.ikres = c->ik_residual; P.dv = c->dv; P.iters = c->solver_iters;
   P.ikiters = c->ik_iters; P.mode = c->mode; P.maxsteps = c->max_episode_steps; P.autoreset = c->auto_reset;
-  P.selfcol = c->enable_self_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed;
+  P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed;
   return P;
 }
 
@@ -211,7 +211,7 @@ extern "C" {
 void pih_default_config(pih_config* c) {
   memset(c, 0, sizeof *c);
   c->n_envs = 1; c->env_index0 = 0; c->mode = 0; c->solver_iters = 50; c->ik_iters = 20; c->max_episode_steps = 2227;
-  c->auto_reset = 0; c->enable_self_collision = 1; c->debug = 0; c->schedule = 1; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
+  c->auto_reset = 0; c->enable_self_collision = 1; c->enable_arm_collision = 1; c->debug = 0; c->schedule = 1; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
   c->erp = 0.2f; c->warmstart = 0.85f; c->contact_margin = 0.005f; c->linear_slop = 1e-5f; c->ik_damping = 0.5f; c->ik_residual = 1e-4f;
   c->dv = 2.0f / 240.0f;
 }

@@ -13,7 +13,7 @@ class PihConfig(C.Structure):
     """Mirror of pih_config (include/pih.h)."""
     _fields_ = [("n_envs", C.c_int32), ("env_index0", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32),
                 ("ik_iters", C.c_int32), ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32),
-                ("enable_self_collision", C.c_int32), ("debug", C.c_int32), ("schedule", C.c_int32), ("seed", C.c_uint64),
+                ("enable_self_collision", C.c_int32), ("debug", C.c_int32), ("schedule", C.c_int32), ("enable_arm_collision", C.c_int32), ("seed", C.c_uint64),
                 ("dt", C.c_float), ("residual_threshold", C.c_float), ("erp", C.c_float), ("warmstart", C.c_float),
                 ("contact_margin", C.c_float), ("linear_slop", C.c_float), ("ik_damping", C.c_float), ("ik_residual", C.c_float),
                 ("dv", C.c_float), ("reserved_f", C.c_float * 3)]
@@ -21,7 +21,7 @@ class PihConfig(C.Structure):
 
 def default_config(**kw):
     c = PihConfig(n_envs=1, env_index0=0, mode=0, solver_iters=50, ik_iters=20, max_episode_steps=2227, auto_reset=0,
-                  enable_self_collision=1, debug=0, seed=0, dt=1.0 / 240.0, residual_threshold=1e-7, erp=0.2, warmstart=0.85,
+                  enable_self_collision=1, enable_arm_collision=1, debug=0, seed=0, dt=1.0 / 240.0, residual_threshold=1e-7, erp=0.2, warmstart=0.85,
                   contact_margin=0.005, linear_slop=1e-5, ik_damping=0.5, ik_residual=1e-4, dv=2.0 / 240.0)
     for k, v in kw.items():
         if not hasattr(c, k):

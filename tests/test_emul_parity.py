@@ -122,3 +122,35 @@ def test_frozen_done_and_auto_reset(oracle_mod):
             assert do.all() and o.get_state()[0, 93] == 5       # frozen after done (envs/base_env.py:62,66)
         else:
             assert o.get_state()[0, 93] == 12 % 5
+
+
+def test_arm_table_contact_f64(oracle_mod):
+    """Arm collision spheres vs the table (keys 3000+): drive the gripper down into the table.  The device algorithm (arm
+    link as linkA, no pipe response) must match the oracle step by step, and the finger tips must stop at the table."""
+    N = 3
+    kw = dict(residual_threshold=0.0, warmstart=0.0)
+    o = oracle_mod.Oracle(N, **kw); e = E.Emul(N, "f64", debug=1, **kw)
+    p0, _ = oracle_mod.fk_arm(REST, 9)
+    seen = 0
+    lowest = 1.0
+    for t in range(420):
+        a = np.tile([p0[0], p0[1] - 0.25, -1.0, 0.04], (N, 1))     # target far below the table, away from the pipe's spawn area... y in [-0.6,-0.4]
+        a[:, 0] += 0.25
+        so = o.get_state(); se = e.get_state(); se[:, :98] = so[:, :98]; se[:, 128] = 0; e.set_state(se)
+        o.step(a); e.step(a)
+        so = o.get_state(); se = e.get_state()
+        keys = [int(k) for k in o.debug_contacts(0)[:, 10]]
+        seen += any(k >= 3000 for k in keys)
+        assert np.abs(so[:, POS] - se[:, POS]).max() < 1e-7, t
+        assert np.abs(so[:, VEL] - se[:, VEL]).max() < 5e-5 * (1 + np.abs(so[:, VEL]).max()), t
+        np.testing.assert_array_equal(o.ncontacts(), se[:, 106].astype(int))
+        ee, _ = oracle_mod.fk_arm(so[0, 0:9], 9)
+        lowest = min(lowest, ee[2])
+    assert seen > 50                       # the arm reached the table and stayed in contact
+    # grasp target is 7 mm above the finger-tip sphere bottoms; the table is at -0.05: the EE cannot sink below it
+    assert lowest > -0.05 - 0.004, lowest
+    # without arm collision the same command drives the gripper through the table
+    o2 = oracle_mod.Oracle(1, enable_arm_collision=0, **kw)
+    for t in range(420):
+        o2.step(a[:1])
+    assert oracle_mod.fk_arm(o2.get_state()[0, 0:9], 9)[0][2] < -0.08

@@ -34,7 +34,7 @@ def test_native_library_loaded(torch_mod):
     import ctypes
     from peg_in_hole_gym_amd import _lib
     L = _lib.load()
-    assert isinstance(L, ctypes.CDLL) and L.pih_abi_version() == 1
+    assert isinstance(L, ctypes.CDLL) and L.pih_abi_version() == 2
 
 
 def test_reset_matches_oracle(torch_mod, oracle_mod):

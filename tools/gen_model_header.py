@@ -180,6 +180,18 @@ print("/* finger pad boxes in finger-link frame (PROVISIONAL stand-in for finger
 print("#define PIH_FINGER_BOX_C {{0.0, 0.010, 0.0295}, {0.0, -0.010, 0.0295}}")
 print("#define PIH_FINGER_BOX_H {0.0105, 0.010, 0.0245}")
 print("#define PIH_FINGER_LINK0 7")
+# arm-vs-table collision spheres (PROVISIONAL stand-in for the Panda collision meshes of pybullet_data, absent): finger tips
+# (the far end of the pad boxes), three hand spheres (hand frame = link7 frame * T(0,0,.107) Rz(-pi/4)), flange, and the
+# origins of panda_link4/5/6.  link index, centre in the link frame, radius
+hs = lambda y, z: tuple(float(v) for v in (np.array([0, 0, 0.107]) + Rh @ np.array([0, y, z])))
+ARM_SPH = [(7, (0.0, 0.010, 0.0435), 0.0105), (8, (0.0, -0.010, 0.0435), 0.0105),
+           (6, hs(0.0, 0.03), 0.035), (6, hs(0.065, 0.03), 0.035), (6, hs(-0.065, 0.03), 0.035), (6, (0.0, 0.0, 0.05), 0.045),
+           (5, (0.0, 0.0, 0.0), 0.055), (4, (0.0, 0.0, 0.0), 0.06), (3, (0.0, 0.0, 0.0), 0.06)]
+print("/* arm-vs-table collision spheres (PROVISIONAL: Panda collision meshes absent) */")
+print("#define PIH_ARM_NSPH %d" % len(ARM_SPH))
+print("#define PIH_ARM_SPH_LINK " + iarr(a[0] for a in ARM_SPH))
+print("#define PIH_ARM_SPH_C {" + ", ".join(arr(a[1]) for a in ARM_SPH) + "}")
+print("#define PIH_ARM_SPH_R " + arr(a[2] for a in ARM_SPH))
 print("/* pipe collision rope */")
 print("#define PIH_PIPE_RADIUS %s" % fmt(PIPE_R))
 print("#define PIH_PIPE_NSAMP %d" % len(samples))
