@@ -30,11 +30,12 @@ namespace pih {
 constexpr int NL = PIH_NL, ANL = PIH_ARM_NL, ONL = PIH_OBJ_NL, ND = PIH_NDOF;
 constexpr int NSAMP = PIH_PIPE_NSAMP;
 constexpr int CMAX = 48;      // contacts per env
-constexpr int CAMAX = 12;     // of which may involve the arm
+constexpr int CAMAX = 12;     // of which may involve the arm (same cap as the oracle's PIHO_CAMAX)
 constexpr int CL = 16;        // contacts whose solver data live in LDS; contacts CL..CMAX-1 spill to a global scratch
 constexpr int NROWC = 3 * CMAX;
 constexpr int CREC = 32;      // words per packed contact record
-constexpr int WPS = 31;       // LDS row stride of the pipe response rows (29 used, odd => conflict free)
+constexpr int WPS = 39;       // LDS row stride of a contact response row: entry d = DOF d (9 arm + 29 pipe), word 38 = 0 (read by idle lanes)
+constexpr int WMS = 31;       // row stride of the staged pipe-motor response rows (29 used)
 constexpr int NMOT = 32;      // 9 arm + 23 pipe joint motors
 constexpr int NLIM = 18;
 
@@ -101,7 +102,7 @@ struct Params {
 PIH_HD int link_dof(int L) { return L < ANL ? L : (L == ANL ? 9 : L + 5); }
 
 // Packed per-contact solver record (CREC = 32 words, 128-bit aligned so the PGS loop reads it with b128 broadcasts):
-//  0-2 p | 3 linkA | 4 linkB | 5 mu | 6 arm-row slot | 7 -
+//  0-2 p | 3 lower bound of the normal row (0, attach: -BIG) | 4 floor of the friction bound (0, attach: +BIG) | 5 mu | 6 - | 7 -
 //  8-10 n | 11 dinv_n | 12-14 t1 | 15 dinv_t1 | 16-18 t2 | 19 dinv_t2
 //  20-22 rhs (n,t1,t2) | 23 G[t1][n] | 24 G[t2][n] | 25 G[t2][t1] | 26-28 dvp_n, then multipliers | 29-31 dvp_t1, then resid*dinv^2
 // (dvp_k = relative velocity change at the contact point per unit impulse along direction k; G[a][b] = dir_a . dvp_b
@@ -117,13 +118,12 @@ struct ArenaA {
   real SP[NSAMP][3];               // collision sample spheres
 };
 struct ArenaB {
-  // response rows of the first CL contacts; the 32 motor response rows (Wmp 23 x WPS, then Wma 9 x 9) are staged in the
+  // response rows of the first CL contacts; the 32 motor response rows (Wmp 23 x WMS, then Wma 9 x 9) are staged in the
   // same words first and pulled into registers before the contact rows overwrite them
   real Wp[3 * CL][WPS];
-  real Wa[3 * CAMAX][9];
   alignas(16) real crec[CL][CREC];
 };
-constexpr int WMA_OFF = PIH_OBJ_NJ * WPS;   // word offset of Wma inside ArenaB::Wp
+constexpr int WMA_OFF = PIH_OBJ_NJ * WMS;   // word offset of Wma inside ArenaB::Wp
 static_assert(WMA_OFF + 81 <= 3 * CL * WPS, "motor response rows must fit in the Wp region");
 
 struct Shared {
@@ -133,7 +133,7 @@ struct Shared {
   real AU[NL][6], ADinv[NL], Au[NL], AR[NL][3];   // U = I^A S, 1/D, u, r = o_L - o_parent
   real Inv6[36];
   real u[ND], udot[ND];
-  int c_la[CMAX], c_lb[CMAX], c_key[CMAX], c_arow[CMAX];
+  int c_la[CMAX], c_lb[CMAX], c_key[CMAX];
   real c_p[CMAX][3], c_n[CMAX][3], c_depth[CMAX], c_mu[CMAX];
   int nc, nca;
   real r_lam[NROWC];
@@ -146,7 +146,7 @@ struct Shared {
   union { ArenaA a; ArenaB b; };
 #ifdef PIH_HOST_EMUL
   real du[ND];
-  real hWmp[PIH_OBJ_NJ][WPS], hWma[9][9];   // host emulation keeps the motor rows in memory (the GPU keeps them in registers)
+  real hWmp[PIH_OBJ_NJ][WMS], hWma[9][9];   // host emulation keeps the motor rows in memory (the GPU keeps them in registers)
 #endif
 };
 // global spill area of one env: response rows and records of contacts CL..CMAX-1
@@ -154,7 +154,7 @@ constexpr int OVF_W_WORDS = 3 * (CMAX - CL) * WPS, OVF_REC_WORDS = (CMAX - CL) *
 struct Ovf { real* base; };
 PIH_HD real* wp_row(Shared& sh, const Ovf& ov, int row) { return row < 3 * CL ? sh.b.Wp[row] : ov.base + (size_t)(row - 3 * CL) * WPS; }
 PIH_HD real* crec_of(Shared& sh, const Ovf& ov, int c) { return c < CL ? sh.b.crec[c] : ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC; }
-PIH_HD real* wmp_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + j * WPS; }
+PIH_HD real* wmp_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + j * WMS; }
 PIH_HD real* wma_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + WMA_OFF + j * 9; }
 
 // ------------------------------------------------------------------------------------------------ wave context
@@ -560,7 +560,7 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
     const int LF = PIH_FINGER_LINK0 + f;
     M3 Rf = ldm(sh.a.LR[LF]); V3 bc = ld3(sh.LO[LF]) + mul(Rf, ld3(FBOX_C[f])); V3 bh = ld3(FBOX_H);
     const int before = w.alloc_count();
-    const int allowed = CAMAX - nca;   // arm-involving contacts are capped (their arm response rows live in Wa)
+    const int allowed = CAMAX - nca;   // arm-involving contacts are capped
     w.par_all(NSAMP, [&](int i, bool in) {
       bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = 0; int L = 0;
       if (in) {
@@ -910,11 +910,6 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
   const real dt = P.dt;
   // link velocities after the free update (contact / motor right-hand sides)
   link_velocities(sh);
-  // arm-row slots of arm-involving contacts, in contact order (wave-uniform scan; nc <= 48)
-  {
-    int na = 0;
-    for (int c = 0; c < sh.nc; c++) { int la = sh.c_la[c], lb = sh.c_lb[c]; bool isarm = (lb >= 0 && lb < ANL) || la < ANL; sh.c_arow[c] = isarm ? na : -1; na += isarm ? 1 : 0; }
-  }
   // motor rows (lane = motor): response of a unit joint impulse; limit rows share W and 1/(J W)
   w.par(NMOT, [&](int m) {
     int L = m < 9 ? m : ANL + 1 + (m - 9);
@@ -953,10 +948,13 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
     V3 t1, t2; plane_space(n, t1, t2);
     V3 dir = k == 0 ? n : (k == 1 ? t1 : t2);
     real* R = crec_of(sh, ov, c);
-    int ar = sh.c_arow[c];
-    RowOut o; o.wp = wp_row(sh, ov, row); o.wa = ar >= 0 ? sh.b.Wa[3 * ar + k] : nullptr;
+    // one full response row per contact row: [arm DOF 0..8 | pipe DOF 9..37 | 0]; the side a contact does not touch is zeroed
+    real* wr = wp_row(sh, ov, row);
+    RowOut o; o.wa = wr; o.wp = wr + 9;
     V3 dvp;
-    if (la < ANL && lb < ANL) { for (int j = 0; j < 29; j++) o.wp[j] = 0; }   // arm-vs-world contact: no pipe response
+    if (!(la < ANL || (lb >= 0 && lb < ANL))) { for (int j = 0; j < 9; j++) wr[j] = 0; }
+    if (!(la >= ANL || lb >= ANL)) { for (int j = 9; j < ND; j++) wr[j] = 0; }
+    wr[ND] = 0;
     real jw = response(sh, la, lb, p, dir, -1, o, &dvp);
     real di = (real)1 / jw;
     V3 vr = point_vel(sh, la, p);
@@ -970,7 +968,8 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
       rhs = (vb - ju) * di;
       int ncache = (int)sh.S[PIH_S_CACHE_N]; real key = (real)sh.c_key[c];
       for (int i = 0; i < ncache; i++) if (sh.S[PIH_S_CACHE_KEY + i] == key) { lam = P.warm * sh.S[PIH_S_CACHE_LAMBDA + i]; break; }
-      R[0] = p.x; R[1] = p.y; R[2] = p.z; R[3] = (real)la; R[4] = (real)lb; R[5] = sh.c_mu[c]; R[6] = (real)ar; R[7] = 0;
+      const bool bil = sh.c_mu[c] < 0;
+      R[0] = p.x; R[1] = p.y; R[2] = p.z; R[3] = bil ? -PIH_BIG : (real)0; R[4] = bil ? PIH_BIG : (real)0; R[5] = sh.c_mu[c]; R[6] = 0; R[7] = 0;
     } else rhs = -ju * di;
     R[8 + 4 * k] = dir.x; R[9 + 4 * k] = dir.y; R[10 + 4 * k] = dir.z; R[11 + 4 * k] = di;
     R[20 + k] = rhs;
@@ -1073,8 +1072,7 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
   DofGeom geo[ND];
   for (int d = 0; d < ND; d++) geo[d] = dof_geom(sh, d);
   auto Wrow = [&](int row, int d) -> real {   // contact-row response entry for dof d
-    if (d >= 9) return wp_row(sh, ov, row)[d - 9];
-    int ar = sh.c_arow[row / 3]; return ar >= 0 ? sh.b.Wa[3 * ar + row % 3][d] : (real)0;
+    return wp_row(sh, ov, row)[d];
   };
   for (int c = 0; c < nc; c++) { real l = sh.r_lam[3 * c]; if (l != 0) for (int d = 0; d < ND; d++) du[d] += Wrow(3 * c, d) * l; }
   real mlam[NMOT], llam[NLIM];
@@ -1128,7 +1126,8 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
   w.sync();
   const int d = w.lane();
   const DofGeom g = dof_geom(sh, d);
-  const bool armlane = d < 9, pipelane = d >= 9 && d < ND;
+  const bool armlane = d < 9;
+  const int dw = d < ND ? d : ND;   // response-row word of this lane (idle lanes read the zero pad)
   // motor / limit multipliers: wave-uniform values held in VGPRs (no readlane, no conditional write-back);
   // contact multipliers: lane-distributed, contact c in lane c
   real lam_p[PIH_OBJ_NJ], lam_a[9], lam_lo[9], lam_hi[9];
@@ -1136,20 +1135,21 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
   for (int j = 0; j < PIH_OBJ_NJ; j++) lam_p[j] = 0;
 #pragma unroll
   for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
-  // per-lane sign of every contact's Jacobian column: bit c of ancA / ancB = this lane's joint is an ancestor of linkA / linkB
-  unsigned long long ancA = 0, ancB = 0;
+  // per-lane sign of every contact's Jacobian column, 2 bits per contact (two's complement: 00 = 0, 01 = +1, 11 = -1, read
+  // back with one v_bfe_i32): +1 if this lane's joint is an ancestor of linkA, -1 of linkB, 0 of both or neither
+  unsigned sg0 = 0, sg1 = 0, sg2 = 0;
+  // Jacobian column of this lane for a point p: cross(ae, p - g.o) + mp  (revolute-like: ae = axis, mp = 0; prismatic-like:
+  // ae = 0, mp = axis; unused lane: both 0) -- no per-contact select
+  const V3 ae = g.kind == 0 ? g.a : mk(0, 0, 0), mp = g.kind == 1 ? g.a : mk(0, 0, 0);
   real du = 0;
   for (int c = 0; c < nc; c++) {
     int la = sh.c_la[c], lb = sh.c_lb[c];
-    if (g.kind != 2 && is_anc(g.L, la)) ancA |= 1ull << c;
-    if (g.kind != 2 && is_anc(g.L, lb)) ancB |= 1ull << c;
+    int sgn = g.kind != 2 ? (int)is_anc(g.L, la) - (int)is_anc(g.L, lb) : 0;
+    unsigned code = (unsigned)sgn & 3u;
+    if (c < 16) sg0 |= code << (2 * c); else if (c < 32) sg1 |= code << (2 * (c - 16)); else sg2 |= code << (2 * (c - 32));
     real l = sh.r_lam[3 * c];   // warm start (uniform LDS read)
     if (l != 0) {
-      int ar = sh.c_arow[c];
-      real wv = 0;
-      if (pipelane) wv = c < CL ? sh.b.Wp[3 * c][d - 9] : ov.base[(size_t)(3 * (c - CL)) * WPS + d - 9];
-      else if (armlane && ar >= 0) wv = sh.b.Wa[3 * ar][d];
-      du += wv * l;
+      du += (c < CL ? sh.b.Wp[3 * c][dw] : ov.base[(size_t)(3 * (c - CL)) * WPS + dw]) * l;
     }
   }
   int it = 0;
@@ -1210,34 +1210,30 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       CRec r;
 #pragma unroll
       for (int i = 0; i < 8; i++) r.q[i] = reinterpret_cast<const real4*>(R)[i];
-      r.w0 = 0; r.w1 = 0; r.w2 = 0;
-      if (pipelane) { r.w0 = wr[d - 9]; r.w1 = wr[WPS + d - 9]; r.w2 = wr[2 * WPS + d - 9]; }
+      r.w0 = wr[dw]; r.w1 = wr[WPS + dw]; r.w2 = wr[2 * WPS + dw];
       return r;
     };
-    auto block = [&](int c, const CRec& r, real* R, bool in_lds) __attribute__((always_inline)) {
-      // q0 = p.xyz, linkA | q1 = linkB, mu, arow, - | q2 = n, dinv_n | q3 = t1, dinv_t1 | q4 = t2, dinv_t2
+    auto block = [&](int c, unsigned sgw, const CRec& r, real* R, bool in_lds) __attribute__((always_inline)) {
+      // q0 = p.xyz, lo_n | q1 = hi_floor, mu, -, - | q2 = n, dinv_n | q3 = t1, dinv_t1 | q4 = t2, dinv_t2
       // q5 = rhs n,t1,t2, G[t1][n] | q6 = G[t2][n], G[t2][t1], lam_n, lam_t1 | q7 = lam_t2, ...
-      real w0 = r.w0, w1 = r.w1, w2 = r.w2;
-      const int ar = (int)r.q[1].z;
-      if (armlane && ar >= 0) { w0 = sh.b.Wa[3 * ar][d]; w1 = sh.b.Wa[3 * ar + 1][d]; w2 = sh.b.Wa[3 * ar + 2][d]; }
-      const V3 p = mk(r.q[0].x, r.q[0].y, r.q[0].z);
+      // (lo_n = 0 / -BIG and hi_floor = 0 / +BIG make the attach rows bilateral without a select)
+      const real w0 = r.w0, w1 = r.w1, w2 = r.w2;
+      const V3 pr = mk(r.q[0].x - g.o.x, r.q[0].y - g.o.y, r.q[0].z - g.o.z);
       const real mu = r.q[1].y;
-      real sgn = (real)(int)((ancA >> c) & 1ull) - (real)(int)((ancB >> c) & 1ull);
-      V3 cv = g.kind == 0 ? cross(g.a, p - g.o) : g.a;
-      real sdu = sgn * du;
+      const real sdu = (real)(int)__builtin_amdgcn_sbfe(sgw, 2u * (unsigned)(c & 15), 2u) * du;
+      const V3 cv = mk(__builtin_fmaf(ae.y, pr.z, __builtin_fmaf(-ae.z, pr.y, mp.x)), __builtin_fmaf(ae.z, pr.x, __builtin_fmaf(-ae.x, pr.z, mp.y)), __builtin_fmaf(ae.x, pr.y, __builtin_fmaf(-ae.y, pr.x, mp.z)));
       real jd0 = sdu * dot(mk(r.q[2].x, r.q[2].y, r.q[2].z), cv), jd1 = sdu * dot(mk(r.q[3].x, r.q[3].y, r.q[3].z), cv), jd2 = sdu * dot(mk(r.q[4].x, r.q[4].y, r.q[4].z), cv);
       row16_sum3(jd0, jd1, jd2);
       rows012_total3(jd0, jd1, jd2);          // valid in lanes 32..47 from here; the scalar chain below runs in plain VGPRs
       const real l0 = r.q[6].z, l1 = r.q[6].w, l2 = r.q[7].x;
       const real di0 = r.q[2].w, di1 = r.q[3].w, di2 = r.q[4].w;
-      const bool bil = mu < 0;                  // attach rows: all three bilateral
       real s0 = l0 + (r.q[5].x - jd0 * di0);
-      s0 = max_(s0, bil ? -PIH_BIG : (real)0);
+      s0 = max_(s0, r.q[0].w);
       real dl0 = s0 - l0;
       worstc = max_(worstc, dl0 * dl0 - r.q[7].y);
       real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
-      if (rdlane(s0, 32) > 0 || rdlane(mu, 32) < 0) {   // wave-uniform branch
-        real hi = bil ? PIH_BIG : mu * s0;
+      if (rdlane(s0, 32) > 0 || rdlane(mu, 32) < 0) {   // wave-uniform branch (Bullet skips the friction rows of an unloaded contact)
+        real hi = max_(mu * s0, r.q[1].x);
         jd1 += r.q[5].w * dl0;
         s1 = l1 + (r.q[5].y - jd1 * di1); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
         worstc = max_(worstc, dl1 * dl1 - r.q[7].z);
@@ -1251,18 +1247,24 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
     };
     const int ncl = nc < CL ? nc : CL;
     if (ncl > 0) {
-      CRec cur = fetch(sh.b.crec[0], &sh.b.Wp[0][0]);
-      for (int c = 0; c < ncl; c++) {
-        const int cn = c + 1 < ncl ? c + 1 : c;
-        CRec nxt = fetch(sh.b.crec[cn], &sh.b.Wp[3 * cn][0]);
-        block(c, cur, sh.b.crec[c], true);
-        cur = nxt;
+      // two-deep ping-pong (ra / rb) instead of "cur = nxt": the rotation of a 27-register record costs 27 v_mov per contact
+      CRec ra = fetch(sh.b.crec[0], &sh.b.Wp[0][0]);
+      int c = 0;
+      for (;;) {
+        const int c1 = c + 1 < ncl ? c + 1 : c;
+        CRec rb = fetch(sh.b.crec[c1], &sh.b.Wp[3 * c1][0]);
+        block(c, sg0, ra, sh.b.crec[c], true);
+        if (++c >= ncl) break;
+        const int c2 = c + 1 < ncl ? c + 1 : c;
+        ra = fetch(sh.b.crec[c2], &sh.b.Wp[3 * c2][0]);
+        block(c, sg0, rb, sh.b.crec[c], true);
+        if (++c >= ncl) break;
       }
     }
     for (int c = CL; c < nc; c++) {
       real* R = ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC;
       CRec r = fetch(R, ov.base + (size_t)(3 * (c - CL)) * WPS);
-      block(c, r, R, false);
+      block(c, c < 32 ? sg1 : sg2, r, R, false);
     }
     worst = max_(worst, rdlane(worstc, 32));
     if (worst <= 0) { it++; break; }

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Issue-slot accounting of pih_step_kernel from the SQ counters (own --pmc passes, no other trace domain):
+#   WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~= WAVE_CYCLES (MI355X_MICROARCH.md, PMC slots); counts are quad-cycles.
+# Usage (GPU box, repo root):  bash tools/pmc_sq.sh <tag>   -> gpurun_out/sq_<tag>.json
+set -e
+TAG=${1:-latest}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU"
+P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_BANK_CONFLICT"
+i=0
+for C in "$P1" "$P2"; do
+  i=$((i+1))
+  rm -rf $R/gpurun_out/sq_${TAG}_$i
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/sq_${TAG}_$i -- python $R/bench.py --steps 30 --warmup 10 --no-cpu-baseline > $R/gpurun_out/sq_${TAG}_$i.bench.json 2> $R/gpurun_out/sq_${TAG}_$i.err
+done
+cd $R && python - "$TAG" <<'PY'
+import csv, glob, json, os, sys
+tag = sys.argv[1]
+out = {"tag": tag, "kernel": "pih_step_kernel", "units": "per launch (SQ cycle counters are quad-cycles summed over waves)"}
+acc = {}
+for f in glob.glob("gpurun_out/sq_%s_*/**/*counter_collection.csv" % tag, recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "pih_step_kernel" in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+for k, v in sorted(acc.items()):
+    out[k] = sum(v) / len(v)
+w = out.get("SQ_WAVE_CYCLES")
+if w:
+    for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_LDS"):
+        if k in out:
+            out["frac_" + k] = out[k] / w
+json.dump(out, open("gpurun_out/sq_%s.json" % tag, "w"), indent=1)
+print(json.dumps(out))
+PY
