@@ -9,7 +9,7 @@
 //
 // What replaces what (paths relative to /root/reference/peg_in_hole_gym/):
 //   fk_*            p.getLinkState                    envs/utils.py:62, envs/peg_in_hole.py:58,115,123
-//   ik_solve        p.calculateInverseKinematics      envs/utils.py:67 (BussIK DLS restated)
+//   ik_chain        p.calculateInverseKinematics      envs/utils.py:67 (BussIK DLS restated)
 //   controller      panda_execute / grasp_process     envs/utils.py:60-68 / envs/peg_in_hole.py:122-212
 //   collide, aba, build_rows, pgs, integrate   p.stepSimulation   envs/base_env.py:64, envs/peg_in_hole.py:108
 //   reset_env       PegInHole.reset                   envs/peg_in_hole.py:227-274
@@ -142,7 +142,6 @@ struct Shared {
   //   lrec[j] = {rhs lower, rhs upper, J W of arm joint j, -}
   alignas(16) real mrec[NMOT][4];
   alignas(16) real lrec[9][4];
-  real ik_T[7][12];
   union { ArenaA a; ArenaB b; };
 #ifdef PIH_HOST_EMUL
   real du[ND];
@@ -361,9 +360,6 @@ template <class C, class W> PIH_HD void ik_chain(W& w, real (*ik_T)[12], const P
 #pragma unroll
   for (int i = 0; i < N; i++) qout[i] = q[i];
 }
-template <class W> PIH_HD void ik_solve(W& w, Shared& sh, const Params& P, const real* q0, V3 tpos, Q4 tq, real* qout) {
-  ik_chain<PandaChain>(w, sh.ik_T, P, q0, tpos, tq, qout);
-}
 
 // ------------------------------------------------------------------------------------------------ reset
 // envs/peg_in_hole.py:227-274 with the RNG draw order of SURVEY.md App. E (own counter RNG).  Wave-uniform.
@@ -403,21 +399,61 @@ PIH_HD void reset_state(real* S, const Params& P, int env_global) {
 }
 
 // ------------------------------------------------------------------------------------------------ controller
-template <class W> PIH_HD void controller(W& w, Shared& sh, const Params& P, const real* action) {
-  real* S = sh.S;
-  V3 eep; M3 eeR; ee_pose(sh, eep, eeR);
-  int posctl_arm = 0; real kp_arm = 0, imp_arm = 1, kp_f = 0, imp_f = 1; int posctl_f = 0;
+// Serial execution context: `par` is a plain loop.  One LANE of pih_pre_kernel runs one env's controller with it (64 envs
+// per wavefront, no wave-uniform replication), and the host emulation uses it for the same function.
+struct Serial {
+  template <class F> PIH_HD void par(int n, F f) {
+#pragma unroll
+    for (int i = 0; i < n; i++) f(i);
+  }
+  PIH_HD void sync() {}
+};
+// end-effector pose of a serial chain
+template <class C> PIH_HD void chain_ee(const real* q, V3& p, M3& Re) {
+  M3 R = ldm(C::base_r()); V3 org = ld3(C::base_t());
+#pragma unroll
+  for (int L = 0; L < C::N; L++) {
+    M3 Tl = mul(ldm(C::rfix(L)), axis_angle(ld3(C::axis(L)), q[L]));
+    org = org + mul(R, ld3(C::tfix(L))); R = mul(R, Tl);
+  }
+  Re = mul(R, ldm(C::ee_r())); p = org + mul(R, ld3(C::ee_t()));
+}
+// getLinkState(pipe, grasp_joint_idx)[0:2] from the state record alone (serial walk down the pipe chain)
+PIH_HD void tip_pose_serial(const real* S, real* out) {
+  const int g = (int)S[PIH_S_GRASP];
+  Q4 qq; qq.x = S[PIH_S_QUAT]; qq.y = S[PIH_S_QUAT + 1]; qq.z = S[PIH_S_QUAT + 2]; qq.w = S[PIH_S_QUAT + 3];
+  M3 R = q_to_m(qq); V3 o = ld3(S + PIH_S_POS);
+  if (g != 0)
+    for (int L = ANL + 1; L < NL; L++) {
+      M3 Tl = mul(ldm(L_RFIX[L]), axis_angle(ld3(L_AXIS[L]), S[PIH_S_QJ + L - ANL - 1]));
+      o = o + mul(R, ld3(L_TFIX[L])); R = mul(R, Tl);
+    }
+  V3 p = o + mul(R, mk(0, g == 0 ? (real)0.045 : (real)0.015, 0));
+  Q4 q = m_to_q(R);
+  out[0] = p.x; out[1] = p.y; out[2] = p.z; out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
+}
+
+// Controller, part 1 (per env, serial): action / state machine -> IK -> joint targets.  Reads and writes the state record
+// only (S[TARGET..], and in scripted mode the state-machine words), so on the GPU it runs one env per LANE in
+// pih_pre_kernel before the step kernel; the IK is 20 strictly sequential 7x7 solves, which as wave-uniform code inside the
+// one-wave-per-env step kernel cost 13 % of the step at 1/64 lane utilisation.
+PIH_HD void controller_targets(real* S, const Params& P, const real* action) {
+  Serial sw;
+  real ikT[7][12];
+  real q[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = S[PIH_S_QARM + i];
+  V3 eep; M3 eeR; chain_ee<PandaChain>(q, eep, eeR);
   if (P.mode == 0) {
     // panda_execute, envs/utils.py:60-68
     V3 tl = mk(action[0] - S[PIH_S_OFFSET], action[1] - S[PIH_S_OFFSET + 1], action[2] - S[PIH_S_OFFSET + 2]);
     V3 tp = vel_constraint(eep, tl, P.dv);
     Q4 tq = quat_from_euler(0, -PIH_PI, 0);
     real qs[7];
-    ik_solve(w, sh, P, S + PIH_S_QARM, tp, tq, qs);
+    ik_chain<PandaChain>(sw, ikT, P, q, tp, tq, qs);
 #pragma unroll
     for (int i = 0; i < 7; i++) S[PIH_S_TARGET + i] = qs[i];
     S[PIH_S_TARGET + 7] = action[3]; S[PIH_S_TARGET + 8] = action[3];
-    posctl_arm = posctl_f = 1; kp_arm = kp_f = 1; imp_arm = imp_f = (real)100000.0 * P.dt;
   } else {
     // random_grasp loop body, envs/peg_in_hole.py:53-112 (update_state :206-212, grasp_process :122-204)
     int st = (int)S[PIH_S_FSM];
@@ -425,7 +461,7 @@ template <class W> PIH_HD void controller(W& w, Shared& sh, const Params& P, con
     const int st_prev = st;
     if (nstep >= FSM_STEPS[st]) { st += 1; nstep = 0; if (st >= 10) st = 0; }
     S[PIH_S_FSM] = (real)st; S[PIH_S_FSMT] = (real)nstep * (real)(1.0 / 240.0);
-    real tip[7]; tip_pose(sh, tip);
+    real tip[7]; tip_pose_serial(S, tip);
     Q4 tornq; tornq.x = tip[3]; tornq.y = tip[4]; tornq.z = tip[5]; tornq.w = tip[6];
     V3 rv = mul(q_to_m(tornq), mk(0, S[PIH_S_RANDY], 0));
     V3 tpos = mk(tip[0], tip[1], tip[2]) + rv;
@@ -441,21 +477,33 @@ template <class W> PIH_HD void controller(W& w, Shared& sh, const Params& P, con
     else if (st == 5) { tp = vel_constraint(eep, hole - mk((real)0.04, 0, 0), P.dv); tq = quat_from_euler(0, -PIH_PI, -PIH_PI); do_ik = 1; }
     else if (st == 6) { tp = hole; tq = quat_from_euler(0, -PIH_PI, -PIH_PI); do_ik = 1; }
     else if (st == 8) { tp = mk((real)0.2, (real)-0.6, (real)0.4); tq = quat_from_euler(0, -PIH_PI, PIH_PI / 2); do_ik = 1; }
-    else if (st == 9) S[PIH_S_DONE] = 1;
     if (do_ik) {
       real qs[7];
-      ik_solve(w, sh, P, S + PIH_S_QARM, tp, tq, qs);
+      ik_chain<PandaChain>(sw, ikT, P, q, tp, tq, qs);
 #pragma unroll
       for (int i = 0; i < 7; i++) S[PIH_S_TARGET + i] = qs[i];
     }
-    if (st >= 1) { posctl_arm = 1; kp_arm = (real)0.1; imp_arm = (real)(5.0 * 240.0) * P.dt; }
-    bool closed = st >= 3 && st < 7;
-    real ft = closed ? (real)0.006 : (real)0.02;
-    posctl_f = 1; kp_f = (real)0.1; imp_f = (closed ? (real)20000 : (real)20) * P.dt;
+    const bool closed = st >= 3 && st < 7;
+    const real ft = closed ? (real)0.006 : (real)0.02;
     S[PIH_S_TARGET + 7] = ft; S[PIH_S_TARGET + 8] = ft;
   }
-  // motor rows: btMultiBodyJointMotor desired velocity = kp (q* - q)/dt (+ qd - kd qd, kd = 1); default load-time
-  // velocity motor (target 0, max impulse 1) on every joint that was never commanded (all 23 pipe joints)
+}
+
+// Controller, part 2 (inside the step kernel): motor rows from the targets in the state record.
+// btMultiBodyJointMotor desired velocity = kp (q* - q)/dt (+ qd - kd qd, kd = 1); default load-time velocity motor
+// (target 0, max impulse 1) on every joint that was never commanded (all 23 pipe joints)
+template <class W> PIH_HD void controller_rows(W& w, Shared& sh, const Params& P) {
+  real* S = sh.S;
+  int posctl_arm = 0; real kp_arm = 0, imp_arm = 1, kp_f = 0, imp_f = 1; int posctl_f = 0;
+  if (P.mode == 0) {
+    posctl_arm = posctl_f = 1; kp_arm = kp_f = 1; imp_arm = imp_f = (real)100000.0 * P.dt;
+  } else {
+    const int st = (int)S[PIH_S_FSM];
+    if (st == 9) S[PIH_S_DONE] = 1;          // set here, not in part 1: the step that reaches state 9 still runs in full
+    if (st >= 1) { posctl_arm = 1; kp_arm = (real)0.1; imp_arm = (real)(5.0 * 240.0) * P.dt; }
+    const bool closed = st >= 3 && st < 7;
+    posctl_f = 1; kp_f = (real)0.1; imp_f = (closed ? (real)20000 : (real)20) * P.dt;
+  }
   w.par(NMOT, [&](int m) {
     real vt = 0, imp = 1;
     if (m < 7) { if (posctl_arm) { vt = kp_arm * (S[PIH_S_TARGET + m] - S[PIH_S_QARM + m]) / P.dt; imp = imp_arm; } }
@@ -1296,7 +1344,12 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, const Ovf& ov, int env, 
   fk_all(w, sh);
   PIH_STAMP(0);
   if (!frozen) {
-    controller(w, sh, P, action);
+#ifdef PIH_HOST_EMUL
+    controller_targets(S, P, action);     // on the GPU pih_pre_kernel has already done this (one env per lane)
+#else
+    (void)action;
+#endif
+    controller_rows(w, sh, P);
     PIH_STAMP(1);
     collide(w, sh, P);
     PIH_STAMP(2);

@@ -18,27 +18,45 @@ using namespace pih;
 // 3x3 PGS block per iteration), and at 4096 envs there are only two rounds of resident waves, so a heavy env that starts
 // late leaves most of the chip idle at the tail.  This single-workgroup counting sort orders the envs by the contact count
 // of their PREVIOUS step (descending); pih_step_kernel maps blockIdx through it.  Results do not depend on block order.
-__global__ void __launch_bounds__(1024) pih_order_kernel(const float* __restrict__ state, int* __restrict__ order, int n) {
-  __shared__ int hist[64], base[64];
+// Launch 1 of a step.  Block 0: longest-job-first dispatch order (counting sort of the envs by their previous-step contact
+// count, most contacts first).  Blocks 1..: the controller (action / state machine -> IK -> joint targets), ONE ENV PER LANE
+// of the block's first wavefront (controller_targets is strictly sequential per env; as wave-uniform code inside the
+// one-wave-per-env step kernel it ran at 1/64 lane utilisation).  The two parts touch disjoint state words.
+constexpr int PRE_THREADS = 256;
+__global__ void __launch_bounds__(PRE_THREADS) pih_pre_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
+                                                               int* __restrict__ order, int n) {
   const int t = threadIdx.x;
-  if (t < 64) hist[t] = 0;
-  __syncthreads();
-  for (int e = t; e < n; e += 1024) {
-    int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
-    k = k < 0 ? 0 : (k > 63 ? 63 : k);
-    atomicAdd(&hist[63 - k], 1);          // bin 0 = most contacts
+  if (blockIdx.x == 0) {
+    if (!order) return;
+    __shared__ int hist[64], base[64];
+    if (t < 64) hist[t] = 0;
+    __syncthreads();
+    for (int e = t; e < n; e += PRE_THREADS) {
+      int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
+      k = k < 0 ? 0 : (k > 63 ? 63 : k);
+      atomicAdd(&hist[63 - k], 1);          // bin 0 = most contacts
+    }
+    __syncthreads();
+    if (t == 0) { int acc = 0; for (int b = 0; b < 64; b++) { base[b] = acc; acc += hist[b]; } }
+    __syncthreads();
+    for (int e = t; e < n; e += PRE_THREADS) {
+      int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
+      k = k < 0 ? 0 : (k > 63 ? 63 : k);
+      order[atomicAdd(&base[63 - k], 1)] = e;
+    }
+    return;
   }
-  __syncthreads();
-  if (t == 0) { int acc = 0; for (int b = 0; b < 64; b++) { base[b] = acc; acc += hist[b]; } }
-  __syncthreads();
-  for (int e = t; e < n; e += 1024) {
-    int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
-    k = k < 0 ? 0 : (k > 63 ? 63 : k);
-    order[atomicAdd(&base[63 - k], 1)] = e;
-  }
+  if (t >= 64) return;
+  const int env = (blockIdx.x - 1) * 64 + t;
+  if (env >= n) return;
+  float* S = state + (size_t)env * PIH_STATE_WORDS;
+  if (!P.autoreset && S[PIH_S_DONE] != 0) return;      // finished envs keep their last values (envs/base_env.py:62,66)
+  float a[4] = {0, 0, 0, 0};
+  if (actions) { a[0] = actions[env * 4]; a[1] = actions[env * 4 + 1]; a[2] = actions[env * 4 + 2]; a[3] = actions[env * 4 + 3]; }
+  controller_targets(S, P, a);
 }
 
-__global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
+__global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __restrict__ state,
                                                       float* __restrict__ obs, float* __restrict__ reward,
                                                       unsigned char* __restrict__ done, float* __restrict__ dbg,
                                                       float* __restrict__ ovf, const int* __restrict__ order) {
@@ -49,12 +67,10 @@ __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __rest
 #pragma unroll
   for (int i = 0; i < PIH_STATE_WORDS / 64; i++) sh.S[lane + 64 * i] = rec[lane + 64 * i];
   __syncthreads();
-  float a[4] = {0, 0, 0, 0};
-  if (actions) { a[0] = actions[env * 4]; a[1] = actions[env * 4 + 1]; a[2] = actions[env * 4 + 2]; a[3] = actions[env * 4 + 3]; }
   float o[5], r; unsigned char d;
   Ovf ov; ov.base = ovf + (size_t)env * OVF_WORDS;
   w.dbg = dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr; w.dbgmode = P.debug;
-  step_env(w, sh, P, ov, env, a, o, &r, &d, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
+  step_env(w, sh, P, ov, env, nullptr, o, &r, &d, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < PIH_STATE_WORDS / 64; i++) rec[lane + 64 * i] = sh.S[lane + 64 * i];
@@ -88,39 +104,33 @@ __global__ void __launch_bounds__(64) pih_init_offsets_kernel(float* __restrict_
   for (int k = 0; k < 3; k++) rec[PIH_S_OFFSET + k] = offsets ? offsets[3 * e + k] : 0.f;
 }
 
-__global__ void __launch_bounds__(64) pih_ik_kernel(Params P, const float* __restrict__ q0, const float* __restrict__ tpos,
+// stand-alone batched IK (envs/utils.py:67,79): one problem per LANE (the solve is strictly sequential)
+__global__ void __launch_bounds__(64) pih_ik_kernel(Params P, int n, const float* __restrict__ q0, const float* __restrict__ tpos,
                                                     const float* __restrict__ tquat, float* __restrict__ qout) {
-  __shared__ Shared sh;
-  const int i = blockIdx.x, lane = threadIdx.x;
-  Wave w; w.l = lane; w.counter = 0;
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Serial sw; float ikT[7][12];
   float q[9];
   for (int k = 0; k < 9; k++) q[k] = q0[i * 9 + k];
   Q4 tq; tq.x = tquat[4 * i]; tq.y = tquat[4 * i + 1]; tq.z = tquat[4 * i + 2]; tq.w = tquat[4 * i + 3];
   float qs[7];
-  ik_solve(w, sh, P, q, mk(tpos[3 * i], tpos[3 * i + 1], tpos[3 * i + 2]), tq, qs);
-  if (lane < 9) {
-    float v = q[7] * (lane == 7) + q[8] * (lane == 8);
-    for (int k = 0; k < 7; k++) v += qs[k] * (lane == k);
-    qout[i * 9 + lane] = v;
-  }
+  ik_chain<PandaChain>(sw, ikT, P, q, mk(tpos[3 * i], tpos[3 * i + 1], tpos[3 * i + 2]), tq, qs);
+  for (int k = 0; k < 7; k++) qout[i * 9 + k] = qs[k];
+  qout[i * 9 + 7] = q[7]; qout[i * 9 + 8] = q[8];
 }
 
-// stand-alone UR5 IK (envs/utils.py:79): q0 float[n,6] -> qout float[n,6]
-__global__ void __launch_bounds__(64) pih_ik_ur5_kernel(Params P, const float* __restrict__ q0, const float* __restrict__ tpos,
+// the same for the UR5 chain (envs/utils.py:79): q0 float[n,6] -> qout float[n,6]
+__global__ void __launch_bounds__(64) pih_ik_ur5_kernel(Params P, int n, const float* __restrict__ q0, const float* __restrict__ tpos,
                                                         const float* __restrict__ tquat, float* __restrict__ qout) {
-  __shared__ float ikT[7][12];
-  const int i = blockIdx.x, lane = threadIdx.x;
-  Wave w; w.l = lane; w.counter = 0;
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Serial sw; float ikT[6][12];
   float q[6];
   for (int k = 0; k < 6; k++) q[k] = q0[i * 6 + k];
   Q4 tq; tq.x = tquat[4 * i]; tq.y = tquat[4 * i + 1]; tq.z = tquat[4 * i + 2]; tq.w = tquat[4 * i + 3];
   float qs[6];
-  ik_chain<Ur5Chain>(w, ikT, P, q, mk(tpos[3 * i], tpos[3 * i + 1], tpos[3 * i + 2]), tq, qs);
-  if (lane < 6) {
-    float v = 0;
-    for (int k = 0; k < 6; k++) v += qs[k] * (lane == k);
-    qout[i * 6 + lane] = v;
-  }
+  ik_chain<Ur5Chain>(sw, ikT, P, q, mk(tpos[3 * i], tpos[3 * i + 1], tpos[3 * i + 2]), tq, qs);
+  for (int k = 0; k < 6; k++) qout[i * 6 + k] = qs[k];
 }
 
 // wrist camera (p12): grid = (strips, envs), 256 threads; out float[count, H, W, 4] = depth, r, g, b
@@ -265,7 +275,7 @@ int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, void* stream) {
 }
 
 static int launch_step(pih_handle* h, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t s) {
-  if (h->order) hipLaunchKernelGGL(pih_order_kernel, dim3(1), dim3(1024), 0, s, h->state, h->order, h->cfg.n_envs);
+  hipLaunchKernelGGL(pih_pre_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->timing) {
     if (h->ev_used == h->ev.size()) {
@@ -276,7 +286,7 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
     e0 = h->ev[h->ev_used].first; e1 = h->ev[h->ev_used].second; h->ev_used++;
     HIPCHK(h, hipEventRecord(e0, s));
   }
-  hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->ovf, h->order);
+  hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, obs, reward, done, h->dbg, h->ovf, h->order);
   if (h->timing) HIPCHK(h, hipEventRecord(e1, s));
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -322,14 +332,14 @@ int pih_set_state(pih_handle* h, int field, const void* in_dev, void* stream) {
 
 int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream) {
   if (!h || n <= 0 || !q0_dev || !tpos_dev || !tquat_dev || !qout_dev) return -2;
-  hipLaunchKernelGGL(pih_ik_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, h->P, q0_dev, tpos_dev, tquat_dev, qout_dev);
+  hipLaunchKernelGGL(pih_ik_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, n, q0_dev, tpos_dev, tquat_dev, qout_dev);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
 
 int pih_ik_ur5(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream) {
   if (!h || n <= 0 || !q0_dev || !tpos_dev || !tquat_dev || !qout_dev) return -2;
-  hipLaunchKernelGGL(pih_ik_ur5_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, h->P, q0_dev, tpos_dev, tquat_dev, qout_dev);
+  hipLaunchKernelGGL(pih_ik_ur5_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, n, q0_dev, tpos_dev, tquat_dev, qout_dev);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -69,14 +69,15 @@ void emul_get_state(void* h, double* out) { Emul* e = (Emul*)h; for (size_t i = 
 void emul_set_state(void* h, const double* in) { Emul* e = (Emul*)h; for (size_t i = 0; i < e->state.size(); i++) e->state[i] = (real)in[i]; }
 void emul_get_debug(void* h, double* out) { Emul* e = (Emul*)h; for (size_t i = 0; i < e->dbg.size(); i++) out[i] = e->dbg[i]; }
 void emul_ik(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout) {
-  static Shared sh; Params P = make_params(c); Wave w;
+  Params P = make_params(c); Serial w; real ikT[7][12];
   real q[9], qo[7]; for (int i = 0; i < 9; i++) q[i] = (real)q0[i];
   Q4 tq; tq.x = (real)tquat[0]; tq.y = (real)tquat[1]; tq.z = (real)tquat[2]; tq.w = (real)tquat[3];
-  ik_solve(w, sh, P, q, mk((real)tpos[0], (real)tpos[1], (real)tpos[2]), tq, qo);
-  for (int i = 0; i < 7; i++) qout[i] = qo[i]; qout[7] = q0[7]; qout[8] = q0[8];
+  ik_chain<PandaChain>(w, ikT, P, q, mk((real)tpos[0], (real)tpos[1], (real)tpos[2]), tq, qo);
+  for (int i = 0; i < 7; i++) qout[i] = qo[i];
+  qout[7] = q0[7]; qout[8] = q0[8];
 }
 void emul_ik_ur5(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout) {
-  static real ikT[7][12]; Params P = make_params(c); Wave w;
+  real ikT[6][12]; Params P = make_params(c); Serial w;
   real q[6], qo[6]; for (int i = 0; i < 6; i++) q[i] = (real)q0[i];
   Q4 tq; tq.x = (real)tquat[0]; tq.y = (real)tquat[1]; tq.z = (real)tquat[2]; tq.w = (real)tquat[3];
   ik_chain<Ur5Chain>(w, ikT, P, q, mk((real)tpos[0], (real)tpos[1], (real)tpos[2]), tq, qo);
