@@ -104,7 +104,7 @@ PIH_HD int link_dof(int L) { return L < ANL ? L : (L == ANL ? 9 : L + 5); }
 // Packed per-contact solver record (CREC = 32 words, 128-bit aligned so the PGS loop reads it with b128 broadcasts):
 //  0-2 p | 3 lower bound of the normal row (0, attach: -BIG) | 4 floor of the friction bound (0, attach: +BIG) | 5 mu | 6 - | 7 -
 //  8-10 n | 11 dinv_n | 12-14 t1 | 15 dinv_t1 | 16-18 t2 | 19 dinv_t2
-//  20-22 rhs (n,t1,t2) | 23 G[t1][n] | 24 G[t2][n] | 25 G[t2][t1] | 26-28 dvp_n, then multipliers | 29-31 dvp_t1, then resid*dinv^2
+//  20-22 rhs (n,t1,t2) | 23 G[t1][n] | 24 G[t2][n] | 25 G[t2][t1] | 26-28 dvp_n, then multipliers | 29-31 dvp_t1, then sqrt(resid)*dinv
 // (dvp_k = relative velocity change at the contact point per unit impulse along direction k; G[a][b] = dir_a . dvp_b
 //  are the cross terms that make the in-block (n, t1, t2) update exact Gauss-Seidel)
 
@@ -138,7 +138,7 @@ struct Shared {
   int nc, nca;
   real r_lam[NROWC];
   // packed motor / limit rows (16-byte records => one broadcast ds_read_b128 per row in the PGS loop):
-  //   mrec[m] = {1/(J W), rhs, resid/(J W)^2 (early-exit threshold), max impulse} ; before build_rows [1] holds the target velocity
+  //   mrec[m] = {1/(J W), rhs, sqrt(resid)/(J W) (early-exit threshold on |d lambda|), max impulse} ; before build_rows [1] holds the target velocity
   //   lrec[j] = {rhs lower, rhs upper, J W of arm joint j, -}
   alignas(16) real mrec[NMOT][4];
   alignas(16) real lrec[9][4];
@@ -965,7 +965,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
     real jw = response(sh, -1, -1, mk(0, 0, 0), mk(0, 0, 0), L, o);
     real di = (real)1 / jw;
     int d = link_dof(L);
-    sh.mrec[m][0] = di; sh.mrec[m][1] = (sh.mrec[m][1] - sh.u[d]) * di; sh.mrec[m][2] = P.resid * di * di;
+    sh.mrec[m][0] = di; sh.mrec[m][1] = (sh.mrec[m][1] - sh.u[d]) * di; sh.mrec[m][2] = (real)sqrt(P.resid) * di;
     if (m < 9) sh.lrec[m][2] = jw;
   });
   w.par(NLIM, [&](int k) {
@@ -1030,7 +1030,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
     V3 t1 = ld3(R + 12), t2 = ld3(R + 16), dn = ld3(R + 26), d1 = ld3(R + 29);
     R[23] = dot(t1, dn); R[24] = dot(t2, dn); R[25] = dot(t2, d1);
     R[26] = sh.r_lam[3 * c]; R[27] = 0; R[28] = 0;   // multipliers (n, t1, t2) live in the record from here on (GPU PGS)
-    R[29] = P.resid * R[11] * R[11]; R[30] = P.resid * R[15] * R[15]; R[31] = P.resid * R[19] * R[19];   // early-exit thresholds resid * dinv^2
+    { const real sr = (real)sqrt(P.resid); R[29] = sr * R[11]; R[30] = sr * R[15]; R[31] = sr * R[19]; }   // early-exit thresholds sqrt(resid) * dinv
   });
 }
 
@@ -1200,9 +1200,12 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       du += (c < CL ? sh.b.Wp[3 * c][dw] : ov.base[(size_t)(3 * (c - CL)) * WPS + dw]) * l;
     }
   }
-  int it = 0;
-  for (; it < P.iters; it++) {
-    real worst = -1;
+  // one PGS iteration; returns true when every row moved by less than its threshold
+  auto iterate = [&]() __attribute__((always_inline)) -> bool {
+    // Early exit (Bullet's least-squares residual test, max over rows of (d lambda / dinv)^2 <= resid) as |d lambda| >
+    // sqrt(resid) dinv per row: one v_cmp into a wave mask + a scalar OR per row instead of an FMA and a max.  Bit 32 is read:
+    // the motor chain is wave-uniform and the contact chain is valid in lanes 32..47.
+    unsigned long long busy = 0;
     // the row constants are re-read from LDS every iteration ON PURPOSE: without this compiler barrier LICM hoists all
     // ~155 loop-invariant loads out of the iteration loop and spills them to scratch inside the hot loop
     __asm__ volatile("" ::: "memory");
@@ -1226,15 +1229,15 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
         real sum = lam_a[j] + (rhs - dj * di);
         sum = med3_(sum, -lim, lim);
         real dl = sum - lam_a[j]; lam_a[j] = sum;
-        worst = max_(worst, dl * dl - thr);
+        busy |= __ballot(absr(dl) > thr);
         dj += dl * wjj;
         real s2 = lam_lo[j] + (lor - dj * di); s2 = max_(s2, (real)0);
         real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
-        worst = max_(worst, d2 * d2 - thr);
+        busy |= __ballot(absr(d2) > thr);
         dj += d2 * wjj;
         real s3 = lam_hi[j] + (hir + dj * di); s3 = max_(s3, (real)0);
         real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
-        worst = max_(worst, d3 * d3 - thr);
+        busy |= __ballot(absr(d3) > thr);
         tot_a = dl + d2 - d3;
       }
       // pipe joint motor j (DOF 15 + j)
@@ -1243,13 +1246,12 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       real sum = lam_p[j] + (rhs - dj * di);
       sum = med3_(sum, -lim, lim);
       real dl = sum - lam_p[j]; lam_p[j] = sum;
-      worst = max_(worst, dl * dl - thr);
+      busy |= __ballot(absr(dl) > thr);
       du += mw.w[j] * (armlane ? tot_a : dl);
     }
     // one exact 3x3 Gauss-Seidel block per contact.  The body is instantiated twice so that the LDS-resident contacts
     // (c < CL) compile to ds_read with immediate offsets and only the rare spilled ones (c >= CL) use global loads; a
     // single loop over "LDS or global" pointers degrades every access to flat_load + vmcnt(0)/lgkmcnt(0) waits.
-    real worstc = -1;
     // Whole record (8 x 16 B) + the three response-row entries of this lane are fetched in ONE batch, and for the
     // LDS-resident contacts the next contact's batch is issued before the current block computes (software pipelining):
     // piecemeal loads cost four serial LDS round trips per contact, which two waves per SIMD cannot hide.
@@ -1278,16 +1280,16 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       real s0 = l0 + (r.q[5].x - jd0 * di0);
       s0 = max_(s0, r.q[0].w);
       real dl0 = s0 - l0;
-      worstc = max_(worstc, dl0 * dl0 - r.q[7].y);
+      busy |= __ballot(absr(dl0) > r.q[7].y);
       real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
       if (rdlane(s0, 32) > 0 || rdlane(mu, 32) < 0) {   // wave-uniform branch (Bullet skips the friction rows of an unloaded contact)
         real hi = max_(mu * s0, r.q[1].x);
         jd1 += r.q[5].w * dl0;
         s1 = l1 + (r.q[5].y - jd1 * di1); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
-        worstc = max_(worstc, dl1 * dl1 - r.q[7].z);
+        busy |= __ballot(absr(dl1) > r.q[7].z);
         jd2 += r.q[6].x * dl0 + r.q[6].y * dl1;
         s2 = l2 + (r.q[5].z - jd2 * di2); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
-        worstc = max_(worstc, dl2 * dl2 - r.q[7].w);
+        busy |= __ballot(absr(dl2) > r.q[7].w);
       }
       if (d == 32) { R[26] = s0; R[27] = s1; R[28] = s2; }
       if (!in_lds) __threadfence_block();     // spilled records live in global memory: make lane 32's store visible to the wave
@@ -1314,8 +1316,15 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       CRec r = fetch(R, ov.base + (size_t)(3 * (c - CL)) * WPS);
       block(c, c < 32 ? sg1 : sg2, r, R, false);
     }
-    worst = max_(worst, rdlane(worstc, 32));
-    if (worst <= 0) { it++; break; }
+    return !((busy >> 32) & 1ull);
+  };
+  // the body is instantiated twice per trip: the multipliers are loop-carried, and with a single copy every new value has
+  // to be moved back into the register the loop header expects (~50 v_mov per iteration)
+  int it = 0;
+  while (it < P.iters) {
+    it++; if (iterate()) break;
+    if (it >= P.iters) break;
+    it++; if (iterate()) break;
   }
   w.sync();
   if (d < nc) { const real* R = d < CL ? sh.b.crec[d] : ov.base + OVF_W_WORDS + (size_t)(d - CL) * CREC; sh.r_lam[3 * d] = R[26]; sh.r_lam[3 * d + 1] = R[27]; sh.r_lam[3 * d + 2] = R[28]; }
