@@ -12,7 +12,7 @@ i=0
 for C in "$P1" "$P2"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/sq_${TAG}_$i
-  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/sq_${TAG}_$i -- python $R/bench.py --steps 30 --warmup 10 --no-cpu-baseline > $R/gpurun_out/sq_${TAG}_$i.bench.json 2> $R/gpurun_out/sq_${TAG}_$i.err
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/sq_${TAG}_$i -- python $R/bench.py --steps 40 --warmup 120 --no-cpu-baseline > $R/gpurun_out/sq_${TAG}_$i.bench.json 2> $R/gpurun_out/sq_${TAG}_$i.err
 done
 cd $R && python - "$TAG" <<'PY'
 import csv, glob, json, os, sys
