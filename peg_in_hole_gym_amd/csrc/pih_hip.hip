@@ -190,7 +190,7 @@ struct pih_handle {
   float* state = nullptr;
   float* dbg = nullptr;
   float* ovf = nullptr;     // spill area for contacts beyond the LDS-resident CL (rarely touched)
-  int* order = nullptr;     // longest-job-first block -> env map (pih_order_kernel)
+  int* order = nullptr;     // longest-job-first block -> env map (block 0 of pih_pre_kernel)
   std::string err;
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // event pairs bracketing each step launch
