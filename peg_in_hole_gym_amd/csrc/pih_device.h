@@ -123,8 +123,10 @@ struct ArenaB {
   real Wp[3 * CL][WPS];
   alignas(16) real crec[CL][CREC];
 };
-constexpr int WMA_OFF = PIH_OBJ_NJ * WMS;   // word offset of Wma inside ArenaB::Wp
-static_assert(WMA_OFF + 81 <= 3 * CL * WPS, "motor response rows must fit in the Wp region");
+constexpr int WMA_OFF = PIH_OBJ_NJ * WMS;   // word offset of Wma inside the staging block
+constexpr int WSTAGE = 3 * CL * WPS - (WMA_OFF + 81);   // the staging block sits at the END of ArenaB::Wp ...
+constexpr int MERGED_CONTACTS = 9;          // ... so the response rows of the first 9 contacts can be written in the same pass
+static_assert(WSTAGE >= 3 * MERGED_CONTACTS * WPS, "motor staging must not overlap the rows of the merged contacts");
 
 struct Shared {
   alignas(16) real S[PIH_STATE_WORDS];
@@ -153,8 +155,8 @@ constexpr int OVF_W_WORDS = 3 * (CMAX - CL) * WPS, OVF_REC_WORDS = (CMAX - CL) *
 struct Ovf { real* base; };
 PIH_HD real* wp_row(Shared& sh, const Ovf& ov, int row) { return row < 3 * CL ? sh.b.Wp[row] : ov.base + (size_t)(row - 3 * CL) * WPS; }
 PIH_HD real* crec_of(Shared& sh, const Ovf& ov, int c) { return c < CL ? sh.b.crec[c] : ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC; }
-PIH_HD real* wmp_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + j * WMS; }
-PIH_HD real* wma_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + WMA_OFF + j * 9; }
+PIH_HD real* wmp_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + WSTAGE + j * WMS; }
+PIH_HD real* wma_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + WSTAGE + WMA_OFF + j * 9; }
 
 // ------------------------------------------------------------------------------------------------ wave context
 #ifdef PIH_HOST_EMUL
@@ -958,72 +960,90 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
   const real dt = P.dt;
   // link velocities after the free update (contact / motor right-hand sides)
   link_velocities(sh);
-  // motor rows (lane = motor): response of a unit joint impulse; limit rows share W and 1/(J W)
-  w.par(NMOT, [&](int m) {
-    int L = m < 9 ? m : ANL + 1 + (m - 9);
-    RowOut o; o.wa = m < 9 ? wma_row(sh, m) : nullptr; o.wp = m < 9 ? nullptr : wmp_row(sh, m - 9);
-    real jw = response(sh, -1, -1, mk(0, 0, 0), mk(0, 0, 0), L, o);
-    real di = (real)1 / jw;
-    int d = link_dof(L);
-    sh.mrec[m][0] = di; sh.mrec[m][1] = (sh.mrec[m][1] - sh.u[d]) * di; sh.mrec[m][2] = (real)sqrt(P.resid) * di;
-    if (m < 9) sh.lrec[m][2] = jw;
-  });
-  w.par(NLIM, [&](int k) {
-    int L = k >> 1, side = k & 1;
-    real q = sh.S[PIH_S_QARM + L];
-    real pen = side == 0 ? q - L_LO[L] : L_HI[L] - q;
-    real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
-    real sg = side == 0 ? (real)1 : (real)-1;
-    sh.lrec[L][side] = (vb - sg * sh.u[L]) * sh.mrec[L][0];
-  });
-  // pull the motor rows out of the staging words before the contact rows overwrite them
+  // Response rows (lane = row): global row g < 32 is a motor row (unit joint impulse; the limit rows share its W and
+  // 1/(J W)), row 32 + 3c + k is row k of contact c (k = 0 normal, 1/2 friction directions).  ONE call site of response()
+  // serves both kinds with per-lane arguments, and the first pass takes the 32 motor rows together with the first 9 contacts
+  // (27 rows: their response rows end below the words the motor rows are staged in), so an env with <= 9 contacts pays for
+  // one sweep of the articulated system instead of two.
+  const int nrows = NMOT + 3 * sh.nc;
+  constexpr int FIRST = NMOT + 3 * MERGED_CONTACTS;
+#pragma nounroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int g0 = pass == 0 ? 0 : FIRST, g1 = pass == 0 ? (nrows < FIRST ? nrows : FIRST) : nrows;
+    if (g1 > g0) w.par(g1 - g0, [&](int i) {
+      const int g = g0 + i;
+      const bool ismotor = g < NMOT;
+      const int row = ismotor ? 0 : g - NMOT, c = row / 3, k = row - 3 * c;
+      int la = -1, lb = -1, jm = -1;
+      V3 p = mk(0, 0, 0), dir = mk(0, 0, 0);
+      RowOut o; o.wa = nullptr; o.wp = nullptr;
+      if (ismotor) {
+        jm = g < 9 ? g : ANL + 1 + (g - 9);
+        if (g < 9) o.wa = wma_row(sh, g); else o.wp = wmp_row(sh, g - 9);
+      } else {
+        la = sh.c_la[c]; lb = sh.c_lb[c];
+        V3 n = ld3(sh.c_n[c]); p = ld3(sh.c_p[c]);
+        V3 t1, t2; plane_space(n, t1, t2);
+        dir = k == 0 ? n : (k == 1 ? t1 : t2);
+        // one full response row per contact row: [arm DOF 0..8 | pipe DOF 9..37 | 0]; the side a contact does not touch is zeroed
+        real* wr = wp_row(sh, ov, row);
+        o.wa = wr; o.wp = wr + 9;
+        if (!(la < ANL || (lb >= 0 && lb < ANL))) { for (int j = 0; j < 9; j++) wr[j] = 0; }
+        if (!(la >= ANL || lb >= ANL)) { for (int j = 9; j < ND; j++) wr[j] = 0; }
+        wr[ND] = 0;
+      }
+      V3 dvp;
+      const real jw = response(sh, la, lb, p, dir, jm, o, &dvp);
+      const real di = (real)1 / jw;
+      if (ismotor) {
+        const int d = link_dof(jm);
+        sh.mrec[g][0] = di; sh.mrec[g][1] = (sh.mrec[g][1] - sh.u[d]) * di; sh.mrec[g][2] = (real)sqrt(P.resid) * di;
+        if (g < 9) sh.lrec[g][2] = jw;
+      } else {
+        real* R = crec_of(sh, ov, c);
+        V3 vr = point_vel(sh, la, p);
+        if (lb >= 0) vr = vr - point_vel(sh, lb, p);
+        real ju = dot(dir, vr);
+        real lam = 0, rhs;
+        if (k == 0) {
+          real pen = sh.c_depth[c] + P.slop;
+          real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
+          if (sh.c_mu[c] < 0) vb = -P.erp * sh.c_depth[c] / dt;   // attach: close the gap with ERP, both signs allowed
+          rhs = (vb - ju) * di;
+          int ncache = (int)sh.S[PIH_S_CACHE_N]; real key = (real)sh.c_key[c];
+          for (int q = 0; q < ncache; q++) if (sh.S[PIH_S_CACHE_KEY + q] == key) { lam = P.warm * sh.S[PIH_S_CACHE_LAMBDA + q]; break; }
+          const bool bil = sh.c_mu[c] < 0;
+          R[0] = p.x; R[1] = p.y; R[2] = p.z; R[3] = bil ? -PIH_BIG : (real)0; R[4] = bil ? PIH_BIG : (real)0; R[5] = sh.c_mu[c]; R[6] = 0; R[7] = 0;
+        } else rhs = -ju * di;
+        R[8 + 4 * k] = dir.x; R[9 + 4 * k] = dir.y; R[10 + 4 * k] = dir.z; R[11 + 4 * k] = di;
+        R[20 + k] = rhs;
+        if (k < 2) { R[26 + 3 * k] = dvp.x; R[27 + 3 * k] = dvp.y; R[28 + 3 * k] = dvp.z; }
+        sh.r_lam[row] = lam;
+      }
+    });
+    if (pass == 0) {
+      w.par(NLIM, [&](int k) {
+        int L = k >> 1, side = k & 1;
+        real q = sh.S[PIH_S_QARM + L];
+        real pen = side == 0 ? q - L_LO[L] : L_HI[L] - q;
+        real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
+        real sg = side == 0 ? (real)1 : (real)-1;
+        sh.lrec[L][side] = (vb - sg * sh.u[L]) * sh.mrec[L][0];
+      });
+      // pull the motor rows out of the staging words before the contact rows of the second pass overwrite them
 #ifdef PIH_HOST_EMUL
-  for (int j = 0; j < PIH_OBJ_NJ; j++) for (int k = 0; k < 29; k++) sh.hWmp[j][k] = wmp_row(sh, j)[k];
-  for (int j = 0; j < 9; j++) for (int k = 0; k < 9; k++) sh.hWma[j][k] = wma_row(sh, j)[k];
-  (void)mw;
+      for (int j = 0; j < PIH_OBJ_NJ; j++) for (int k = 0; k < 29; k++) sh.hWmp[j][k] = wmp_row(sh, j)[k];
+      for (int j = 0; j < 9; j++) for (int k = 0; k < 9; k++) sh.hWma[j][k] = wma_row(sh, j)[k];
+      (void)mw;
 #else
-  {
-    const int d = w.lane();
+      {
+        const int d = w.lane();
 #pragma unroll
-    for (int j = 0; j < PIH_OBJ_NJ; j++) mw.w[j] = d < 9 ? (j < 9 ? wma_row(sh, j)[d] : (real)0) : (d < ND ? wmp_row(sh, j)[d - 9] : (real)0);
-  }
+        for (int j = 0; j < PIH_OBJ_NJ; j++) mw.w[j] = d < 9 ? (j < 9 ? wma_row(sh, j)[d] : (real)0) : (d < ND ? wmp_row(sh, j)[d - 9] : (real)0);
+      }
 #endif
-  // contact rows (lane = row): row 3c+k, k = 0 normal, 1/2 friction directions; results go straight into the packed record
-  w.par(3 * sh.nc, [&](int row) {
-    int c = row / 3, k = row - 3 * c;
-    int la = sh.c_la[c], lb = sh.c_lb[c];
-    V3 n = ld3(sh.c_n[c]), p = ld3(sh.c_p[c]);
-    V3 t1, t2; plane_space(n, t1, t2);
-    V3 dir = k == 0 ? n : (k == 1 ? t1 : t2);
-    real* R = crec_of(sh, ov, c);
-    // one full response row per contact row: [arm DOF 0..8 | pipe DOF 9..37 | 0]; the side a contact does not touch is zeroed
-    real* wr = wp_row(sh, ov, row);
-    RowOut o; o.wa = wr; o.wp = wr + 9;
-    V3 dvp;
-    if (!(la < ANL || (lb >= 0 && lb < ANL))) { for (int j = 0; j < 9; j++) wr[j] = 0; }
-    if (!(la >= ANL || lb >= ANL)) { for (int j = 9; j < ND; j++) wr[j] = 0; }
-    wr[ND] = 0;
-    real jw = response(sh, la, lb, p, dir, -1, o, &dvp);
-    real di = (real)1 / jw;
-    V3 vr = point_vel(sh, la, p);
-    if (lb >= 0) vr = vr - point_vel(sh, lb, p);
-    real ju = dot(dir, vr);
-    real lam = 0, rhs;
-    if (k == 0) {
-      real pen = sh.c_depth[c] + P.slop;
-      real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
-      if (sh.c_mu[c] < 0) vb = -P.erp * sh.c_depth[c] / dt;   // attach: close the gap with ERP, both signs allowed
-      rhs = (vb - ju) * di;
-      int ncache = (int)sh.S[PIH_S_CACHE_N]; real key = (real)sh.c_key[c];
-      for (int i = 0; i < ncache; i++) if (sh.S[PIH_S_CACHE_KEY + i] == key) { lam = P.warm * sh.S[PIH_S_CACHE_LAMBDA + i]; break; }
-      const bool bil = sh.c_mu[c] < 0;
-      R[0] = p.x; R[1] = p.y; R[2] = p.z; R[3] = bil ? -PIH_BIG : (real)0; R[4] = bil ? PIH_BIG : (real)0; R[5] = sh.c_mu[c]; R[6] = 0; R[7] = 0;
-    } else rhs = -ju * di;
-    R[8 + 4 * k] = dir.x; R[9 + 4 * k] = dir.y; R[10 + 4 * k] = dir.z; R[11 + 4 * k] = di;
-    R[20 + k] = rhs;
-    if (k < 2) { R[26 + 3 * k] = dvp.x; R[27 + 3 * k] = dvp.y; R[28 + 3 * k] = dvp.z; }
-    sh.r_lam[row] = lam;
-  });
+    }
+  }
   // cross terms of each contact block (lane = contact)
   w.par(sh.nc, [&](int c) {
     real* R = crec_of(sh, ov, c);
