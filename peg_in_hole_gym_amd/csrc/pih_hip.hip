@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64) pih_ik_ur5_kernel(Params P, int n, const f
   for (int k = 0; k < 6; k++) qout[i * 6 + k] = qs[k];
 }
 
-// wrist camera (p12): grid = (strips, envs), 256 threads; out float[count, H, W, 4] = depth, r, g, b
+// wrist camera (p12): grid = (strips, envs), 256 threads (4 waves); out float[count, H, W, 4] = depth, r, g, b
 __global__ void __launch_bounds__(RENDER_THREADS) pih_render_kernel(const float* __restrict__ state, float* __restrict__ out,
                                                                     int env_begin, int W, int H, int rows_per_strip) {
   __shared__ Shared sh;
@@ -144,15 +144,26 @@ __global__ void __launch_bounds__(RENDER_THREADS) pih_render_kernel(const float*
   const float* rec = state + (size_t)env * PIH_STATE_WORDS;
   for (int i = tid; i < PIH_STATE_WORDS; i += RENDER_THREADS) sh.S[i] = rec[i];
   __syncthreads();
+  scene_setup(w, sh, sc, tid);
   const float T = PIH_CAM_TANH2, sy = 2.0f / H, sx = 2.0f / W;
-  // camera-plane v of the strip's top and bottom pixel edges (row 0 is the top of the image)
-  scene_setup(w, sh, sc, tid, (1.0f - sy * r1) * T, (1.0f - sy * r0) * T);
   float4* img = reinterpret_cast<float4*>(out) + (size_t)e * H * W;
-  const int p0 = r0 * W, p1 = r1 * W;
-  for (int p = p0 + tid; p < p1; p += RENDER_THREADS) {
-    int i = p / W, j = p - i * W;
-    real4 c = shade(sc, (sx * (j + 0.5f) - 1.0f) * T, (1.0f - sy * (i + 0.5f)) * T);
-    img[p] = make_float4(c.x, c.y, c.z, c.w);
+  constexpr int TR = 16, TC = 64;                   // tile = 16 rows x 64 columns, one row of a tile per wave instruction
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tcols = (W + TC - 1) / TC, trows = (r1 - r0 + TR - 1) / TR;
+  for (int tile = wave; tile < tcols * trows; tile += RENDER_THREADS / 64) {
+    const int ti = tile / tcols, tj = tile - ti * tcols;
+    const int i0 = r0 + ti * TR, i1 = min(r1, i0 + TR), j0 = tj * TC, j1 = min(W, j0 + TC);
+    // camera-plane rectangle of the tile's pixel edges (row 0 is the top of the image, v grows upwards)
+    const float tu0 = (sx * j0 - 1.0f) * T, tu1 = (sx * j1 - 1.0f) * T, tv0 = (1.0f - sy * i1) * T, tv1 = (1.0f - sy * i0) * T;
+    const unsigned prims = (unsigned)__ballot(prim_on_tile(sc, lane, tu0, tu1, tv0, tv1));
+    const int j = j0 + lane;
+    if (j < j1) {
+      const float xc = (sx * (j + 0.5f) - 1.0f) * T;
+      for (int i = i0; i < i1; i++) {
+        real4 c = shade(sc, prims, xc, (1.0f - sy * (i + 0.5f)) * T);
+        img[i * W + j] = make_float4(c.x, c.y, c.z, c.w);
+      }
+    }
   }
 }
 
@@ -350,8 +361,13 @@ int pih_render(pih_handle* h, float* out_dev, int width, int height, int env_beg
     return -2;
   }
   if ((reinterpret_cast<uintptr_t>(out_dev) & 15) != 0) { h->err = "pih_render: out_dev must be 16-byte aligned"; return -2; }
-  // strips of ~32 rows: each workgroup amortises one forward-kinematics pass over >= 32 * width pixels
-  int rows = 32, strips = (height + rows - 1) / rows;
+  // every workgroup runs the forward kinematics of its env once: few strips per env when the batch alone gives the chip
+  // several rounds of workgroups (>= 8192: images differ ~3x in cost, the tail matters), more strips for small batches
+  int strips = (8192 + env_count - 1) / env_count;
+  const int max_strips = (height + 31) / 32;
+  strips = strips < 1 ? 1 : (strips > max_strips ? max_strips : strips);
+  const int rows = ((height + strips - 1) / strips + 15) / 16 * 16;
+  strips = (height + rows - 1) / rows;
   if (env_count > 65535) { h->err = "pih_render: env_count > 65535 per call"; return -2; }
   hipLaunchKernelGGL(pih_render_kernel, dim3(strips, env_count), dim3(RENDER_THREADS), 0, (hipStream_t)stream, h->state, out_dev, env_begin, width, height, rows);
   HIPCHK(h, hipGetLastError());

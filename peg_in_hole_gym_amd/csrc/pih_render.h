@@ -7,9 +7,11 @@
 // 24 pipe capsules (r = 1 cm), the hole tube, the two finger-pad boxes.  TinyRenderer's shading is not reproduced: RGB is
 // one flat value per object (see oracle/pih_oracle.c piho_render, the checker of this file).
 //
-// Mapping: one 256-thread workgroup per (env, strip of rows).  The workgroup runs the forward kinematics once, lane 0..23
-// projects the capsules and keeps those whose screen-space bound touches the strip (LDS list), then every thread shades
-// pixels of the strip (consecutive threads = consecutive pixels => one coalesced 16-byte store per pixel).
+// Mapping: one 256-thread workgroup per (env, strip of rows); the number of strips per env shrinks as the env count grows, so
+// that a full batch runs the forward kinematics once per env.  Each WAVE walks 16-row x 64-column pixel tiles of the strip:
+// lanes 0..26 test the screen-space bound of "their" primitive (24 capsules, 2 finger boxes, the tube) against the tile, the
+// ballot of that test is the tile's primitive list (iterated with scalar bit scans, no LDS list), and one tile row = 64
+// consecutive pixels = one coalesced 1 KB store.  Most tiles see the table plane and 0-2 capsules.
 #pragma once
 #include "pih_device.h"
 
@@ -18,12 +20,13 @@ namespace pih {
 constexpr int RENDER_THREADS = 256;
 constexpr int NSEG = 24;
 
+constexpr int NPRIM = NSEG + 3;             // 24 capsules, 2 finger boxes, hole tube
 struct Scene {
   real eye[3];
   real vtx[NSEG + 1][3];
   real fR[2][9], fc[2][3];
-  int seg[NSEG]; int nseg;
-  int box_on[2], tube_on;
+  real bnd[NPRIM][4];                       // screen-space bound (u0, u1, v0, v1) of every primitive; u0 > u1 = "always on"
+  real bc[2][8][3];                         // finger-box corners relative to the eye (the boxes sit BESIDE the eye: no finite bound)
 };
 
 #define PIH_CAM_NEAR ((real)0.001)
@@ -102,14 +105,11 @@ PIH_HD bool sphere_bound(V3 rel, real r, real& u0, real& u1, real& v0, real& v1)
   return true;
 }
 
-// Scene set-up for one strip [yc_lo, yc_hi] (camera-plane v range of the strip, v grows upwards).  All threads call it.
-template <class W> PIH_HD void scene_setup(W& w, Shared& sh, Scene& sc, int tid, real v_lo, real v_hi) {
+// Scene set-up (all threads of the workgroup call it): forward kinematics, primitive poses and their screen-space bounds.
+template <class W> PIH_HD void scene_setup(W& w, Shared& sh, Scene& sc, int tid) {
   fk_all(w, sh);
   w.sync();
-  if (tid == 0) {
-    V3 p; M3 R; ee_pose(sh, p, R); st3(sc.eye, p);
-    sc.nseg = 0;
-  }
+  if (tid == 0) { V3 p; M3 R; ee_pose(sh, p, R); st3(sc.eye, p); }
   if (tid < NSAMP && SAMP_VERTEX[tid]) {
     int k = 0;
     for (int i = 0; i < tid; i++) k += SAMP_VERTEX[i];
@@ -123,40 +123,49 @@ template <class W> PIH_HD void scene_setup(W& w, Shared& sh, Scene& sc, int tid,
   }
   w.sync();
   const V3 eye = ld3(sc.eye);
-  const real T = PIH_CAM_TANH2;
-  if (tid < NSEG) {
-    real a0, a1, b0, b1, c0, c1, d0, d1;
-    bool ok = sphere_bound(ld3(sc.vtx[tid]) - eye, PIH_PIPE_RADIUS, a0, a1, b0, b1) &&
-              sphere_bound(ld3(sc.vtx[tid + 1]) - eye, PIH_PIPE_RADIUS, c0, c1, d0, d1);
-    bool on = true;
-    if (ok) {
-      real u0 = a0 < c0 ? a0 : c0, u1 = a1 > c1 ? a1 : c1, v0 = b0 < d0 ? b0 : d0, v1 = b1 > d1 ? b1 : d1;
-      on = !(u1 < -T || u0 > T || v1 < v_lo || v0 > v_hi);
+  if (tid < NPRIM) {
+    real u0 = 1, u1 = -1, v0 = 1, v1 = -1;          // "cannot bound": keep for every tile
+    if (tid < NSEG) {
+      real a0, a1, b0, b1, c0, c1, d0, d1;
+      if (sphere_bound(ld3(sc.vtx[tid]) - eye, PIH_PIPE_RADIUS, a0, a1, b0, b1) && sphere_bound(ld3(sc.vtx[tid + 1]) - eye, PIH_PIPE_RADIUS, c0, c1, d0, d1)) {
+        u0 = a0 < c0 ? a0 : c0; u1 = a1 > c1 ? a1 : c1; v0 = b0 < d0 ? b0 : d0; v1 = b1 > d1 ? b1 : d1;
+      }
+    } else if (tid < NSEG + 2) {                    // finger boxes: corners, tested against each tile's frustum (prim_on_tile)
+      const int f = tid - NSEG;
+      const M3 R = ldm(sc.fR[f]); const V3 c = ld3(sc.fc[f]) - eye, h = ld3(FBOX_H);
+      for (int k = 0; k < 8; k++)
+        st3(sc.bc[f][k], c + mul(R, mk((k & 1) ? h.x : -h.x, (k & 2) ? h.y : -h.y, (k & 4) ? h.z : -h.z)));
+    } else {                                        // hole tube: bounding sphere
+      real a0, a1, b0, b1;
+      real rad = (real)sqrt(PIH_HOLE_HALFLEN * PIH_HOLE_HALFLEN + PIH_HOLE_ROUT * PIH_HOLE_ROUT);
+      if (sphere_bound(ld3(HOLE_POS) - eye, rad, a0, a1, b0, b1)) { u0 = a0; u1 = a1; v0 = b0; v1 = b1; }
     }
-#ifdef PIH_HOST_EMUL
-    if (on) sc.seg[sc.nseg++] = tid;
-#else
-    if (on) sc.seg[atomicAdd(&sc.nseg, 1)] = tid;
-#endif
-  }
-  if (tid >= 32 && tid < 34) {            // finger boxes: bounding sphere of the box
-    int f = tid - 32;
-    V3 h = ld3(FBOX_H);
-    real a0, a1, b0, b1;
-    bool ok = sphere_bound(ld3(sc.fc[f]) - eye, norm(h), a0, a1, b0, b1);
-    sc.box_on[f] = !ok || !(a1 < -T || a0 > T || b1 < v_lo || b0 > v_hi);
-  }
-  if (tid == 34) {                        // hole tube: bounding sphere
-    real a0, a1, b0, b1;
-    real rad = (real)sqrt(PIH_HOLE_HALFLEN * PIH_HOLE_HALFLEN + PIH_HOLE_ROUT * PIH_HOLE_ROUT);
-    bool ok = sphere_bound(ld3(HOLE_POS) - eye, rad, a0, a1, b0, b1);
-    sc.tube_on = !ok || !(a1 < -T || a0 > T || b1 < v_lo || b0 > v_hi);
+    sc.bnd[tid][0] = u0; sc.bnd[tid][1] = u1; sc.bnd[tid][2] = v0; sc.bnd[tid][3] = v1;
   }
   w.sync();
 }
 
-// one pixel: xc, yc = camera-plane coordinates of the pixel centre (already multiplied by tan(fov/2))
-PIH_HD real4 shade(const Scene& sc, real xc, real yc) {
+// does primitive `i` (this lane's) touch the tile [tu0, tu1] x [tv0, tv1] of the camera plane?
+PIH_HD bool prim_on_tile(const Scene& sc, int i, real tu0, real tu1, real tv0, real tv1) {
+  if (i >= NPRIM) return false;
+  if (i >= NSEG && i < NSEG + 2) {
+    // convex box vs the tile's frustum {|x| <= u d, |y| <= v d, d = depth}: invisible if all 8 corners lie outside one of the
+    // four side planes (homogeneous form, valid for corners beside or behind the eye)
+    bool o0 = true, o1 = true, o2 = true, o3 = true;
+    for (int k = 0; k < 8; k++) {
+      const real x = sc.bc[i - NSEG][k][0], y = sc.bc[i - NSEG][k][1], dpt = -sc.bc[i - NSEG][k][2];
+      o0 = o0 && (x - tu1 * dpt > 0); o1 = o1 && (x - tu0 * dpt < 0); o2 = o2 && (y - tv1 * dpt > 0); o3 = o3 && (y - tv0 * dpt < 0);
+    }
+    return !(o0 || o1 || o2 || o3);
+  }
+  const real u0 = sc.bnd[i][0], u1 = sc.bnd[i][1], v0 = sc.bnd[i][2], v1 = sc.bnd[i][3];
+  if (u0 > u1) return true;
+  return !(u1 < tu0 || u0 > tu1 || v1 < tv0 || v0 > tv1);
+}
+
+// one pixel: xc, yc = camera-plane coordinates of the pixel centre (already multiplied by tan(fov/2)); prims = bit i set if
+// primitive i may cover the pixel (wave-uniform)
+PIH_HD real4 shade(const Scene& sc, unsigned prims, real xc, real yc) {
   const V3 eye = ld3(sc.eye);
   real inv = rsqrt_((real)1 + xc * xc + yc * yc);
   V3 d = mk(xc * inv, yc * inv, -inv);
@@ -165,18 +174,18 @@ PIH_HD real4 shade(const Scene& sc, real xc, real yc) {
     real t = (PIH_TABLE_Z - eye.z) / d.z;
     if (t > 0) { best = t; col = PIH_COL_TABLE; }
   }
-  const int ns = sc.nseg;
-  for (int k = 0; k < ns; k++) {
-    int s = sc.seg[k];
-    real t = ray_capsule(eye, d, ld3(sc.vtx[s]), ld3(sc.vtx[s + 1]), PIH_PIPE_RADIUS);
+  unsigned segs = prims & ((1u << NSEG) - 1u);
+  while (segs) {
+    const int sidx = __builtin_ctz(segs); segs &= segs - 1u;
+    real t = ray_capsule(eye, d, ld3(sc.vtx[sidx]), ld3(sc.vtx[sidx + 1]), PIH_PIPE_RADIUS);
     if (t < best) { best = t; col = PIH_COL_PIPE; }
   }
-  if (sc.tube_on) {
+  if (prims & (1u << (NSEG + 2))) {
     real t = ray_tube(eye, d);
     if (t < best) { best = t; col = PIH_COL_PIPE; }
   }
   for (int f = 0; f < 2; f++)
-    if (sc.box_on[f]) {
+    if (prims & (1u << (NSEG + f))) {
       real t = ray_box(eye, d, ldm(sc.fR[f]), ld3(sc.fc[f]), ld3(FBOX_H));
       if (t < best) { best = t; col = PIH_COL_FINGER; }
     }
