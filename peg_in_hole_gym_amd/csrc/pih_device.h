@@ -740,98 +740,100 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
     I[21] = n.x; I[22] = n.y; I[23] = n.z; I[24] = f.x; I[25] = f.y; I[26] = f.z; I[27] = 0;
   });
   w.stamp(9);
-  // inward sweep (wave-uniform).  The running articulated inertia / bias force of the chain is carried in registers
-  // (`carry` = contribution of the already-visited child, translated to this link's origin); only the link's own
-  // inertia is read from LDS (7 x b128).  The arm's two fingers (links 7, 8) both feed link 6: finger 8 is parked in `hold`.
-  // Symmetric storage throughout: A, C as 6 unique entries (xx yy zz xy xz yz), B full 3x3  => ~180 FMAs per link.
-  struct Acc { S3 A; M3 B; S3 C; V3 pa, pl; };
-  auto zero_acc = []() { Acc z; z.A = S3{0, 0, 0, 0, 0, 0}; z.C = z.A; for (int i = 0; i < 9; i++) z.B.m[i] = 0; z.pa = mk(0, 0, 0); z.pl = z.pa; return z; };
-  Acc carry = zero_acc(), hold = zero_acc();
+  // Inward sweep, LANE = ENTRY of the articulated inertia: lane l < 48 owns entry (i, j) = (l >> 3, l & 7) of the 6 x 8 array
+  // [ I^A (6 x 6, rows/cols 0-2 angular, 3-5 linear, i.e. [[A, B], [B^T, C]]) | p^A (column 6) | - ].  Per link four short
+  // lane-parallel phases exchange entries through three 48-word LDS scratch arrays (Mx = running I^A, Cy = I^a of this link,
+  // Hd = the parked second finger; they alias r_lam, which is dead until the rows are built) instead of ~300 wave-uniform
+  // instructions per link:
+  //   1. Mx = own inertia of the link + what the child handed up
+  //   2. U = I^A S  (S = [a; 0] revolute, [0; a] prismatic), D = S.U, u = tau - S.p^A
+  //   3. Cy = I^a = I^A - U U^T / D ;  column 6 = p^a = p^A + I^a c + U u / D
+  //   4. Mx = Cy translated to the parent's origin (r = o_L - o_parent):  B' = B + [r]x C,  A' = A + [r]x B^T - B' [r]x,
+  //      p_a' = p_a + r x p_l   (entry formulas: ([r]x X)_ij = r_i1 X_i2,j - r_i2 X_i1,j ; (X [r]x)_ij = X_i,j1 r_j2 - X_i,j2 r_j1)
+  // The arm's two fingers (links 7, 8) both feed link 6: finger 8's hand-up is parked in Hd.
+  real* const Mx = sh.r_lam; real* const Cy = sh.r_lam + 48; real* const Hd = sh.r_lam + 96; real* const Uv = sh.udot;
+  static_assert(NROWC >= 144, "scratch of the inward sweep aliases r_lam");
   areal rootp[6] = {0, 0, 0, 0, 0, 0};
   for (int L = NL - 1; L >= 0; L--) {
-    int p = L_PARENT[L], jt = L_JTYPE[L];
+    const int p = L_PARENT[L], jt = L_JTYPE[L];
     const bool leaf = (L == NL - 1) || (L == ANL - 1) || (L == ANL - 2);
-    real own[28];
-#pragma unroll
-    for (int i = 0; i < 7; i++) { real4 v = reinterpret_cast<const real4*>(sh.a.IAP[L])[i]; own[4 * i] = v.x; own[4 * i + 1] = v.y; own[4 * i + 2] = v.z; own[4 * i + 3] = v.w; }
-    S3 A = S3{own[0], own[1], own[2], own[3], own[4], own[5]};
-    M3 B; for (int i = 0; i < 9; i++) B.m[i] = own[6 + i];
-    S3 C = S3{own[15], own[16], own[17], own[18], own[19], own[20]};
-    V3 pa = mk(own[21], own[22], own[23]), pl = mk(own[24], own[25], own[26]);
-    if (!leaf) {
-      A.xx += carry.A.xx; A.yy += carry.A.yy; A.zz += carry.A.zz; A.xy += carry.A.xy; A.xz += carry.A.xz; A.yz += carry.A.yz;
-      C.xx += carry.C.xx; C.yy += carry.C.yy; C.zz += carry.C.zz; C.xy += carry.C.xy; C.xz += carry.C.xz; C.yz += carry.C.yz;
-      for (int i = 0; i < 9; i++) B.m[i] += carry.B.m[i];
-      pa = pa + carry.pa; pl = pl + carry.pl;
-    }
+    w.par(48, [&](int l) {
+      const int i = l >> 3, j = l & 7;
+      // word of the packed record IAP[L] (A6 sym | B9 | C6 sym | p_a 3 | p_l 3 | 0) that holds entry (i, j)
+      const int ii = i < 3 ? i : i - 3, jj = j < 3 ? j : j - 3;
+      const int sym = ii == jj ? ii : ii + jj + 2;                    // xx yy zz xy xz yz
+      int off;
+      if (j >= 7) off = 27;
+      else if (j == 6) off = 21 + i;
+      else if (i < 3 && j < 3) off = sym;
+      else if (i >= 3 && j >= 3) off = 15 + sym;
+      else if (i < 3) off = 6 + 3 * i + jj;                           // B[i][j-3]
+      else off = 6 + 3 * j + ii;                                      // B^T: B[j][i-3]
+      const real own = sh.a.IAP[L][off];
+      Mx[l] = leaf ? own : own + Mx[l];
+    });
     if (jt == PIH_JT_FLOATING) {
-      // root: invert the 6x6 articulated inertia [[A,B],[B^T,C]] (order: angular, linear) by Gauss-Jordan (SPD)
-      M3 Am = s3_to_m(A), Cm = s3_to_m(C);
-      areal Mx[6][6], Iv[6][6];
-      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Mx[i][j] = Am.m[3 * i + j]; Mx[i][3 + j] = B.m[3 * i + j]; Mx[3 + i][j] = B.m[3 * j + i]; Mx[3 + i][3 + j] = Cm.m[3 * i + j]; }
-      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Iv[i][j] = i == j ? (areal)1 : (areal)0;
+      // root: invert the 6x6 articulated inertia (order: angular, linear) by Gauss-Jordan (SPD), wave-uniform
+      areal Mq[6][6], Iv[6][6];
+      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { Mq[i][j] = Mx[8 * i + j]; Iv[i][j] = i == j ? (areal)1 : (areal)0; }
 #pragma unroll
       for (int k = 0; k < 6; k++) {
-        areal pv = (areal)1 / Mx[k][k];
+        areal pv = (areal)1 / Mq[k][k];
 #pragma unroll
-        for (int j = 0; j < 6; j++) { Mx[k][j] *= pv; Iv[k][j] *= pv; }
+        for (int j = 0; j < 6; j++) { Mq[k][j] *= pv; Iv[k][j] *= pv; }
 #pragma unroll
         for (int i = 0; i < 6; i++) if (i != k) {
-          areal f = Mx[i][k];
+          areal f = Mq[i][k];
 #pragma unroll
-          for (int j = 0; j < 6; j++) { Mx[i][j] -= f * Mx[k][j]; Iv[i][j] -= f * Iv[k][j]; }
+          for (int j = 0; j < 6; j++) { Mq[i][j] -= f * Mq[k][j]; Iv[i][j] -= f * Iv[k][j]; }
         }
       }
-      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.Inv6[6 * i + j] = (real)Iv[i][j];
-      rootp[0] = pa.x; rootp[1] = pa.y; rootp[2] = pa.z; rootp[3] = pl.x; rootp[4] = pl.y; rootp[5] = pl.z;
+      for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) sh.Inv6[6 * i + j] = (real)Iv[i][j]; rootp[i] = Mx[8 * i + 6]; }
       continue;
     }
+    const int sb = jt == PIH_JT_REVOLUTE ? 0 : 3;
     const V3 a = ld3(sh.LA[L]);
-    V3 Ua, Ul; real D, u;
+    w.par(6, [&](int i) { Uv[i] = Mx[8 * i + sb] * a.x + Mx[8 * i + sb + 1] * a.y + Mx[8 * i + sb + 2] * a.z; });
     const real tau = -L_DAMPING[L] * sh.u[link_dof(L)];
-    if (jt == PIH_JT_REVOLUTE) { Ua = mul(A, a); Ul = tmul(B, a); D = dot(a, Ua); u = tau - dot(a, pa); }
-    else { Ua = mul(B, a); Ul = mul(C, a); D = dot(a, Ul); u = tau - dot(a, pl); }
+    const real D = a.x * Uv[sb] + a.y * Uv[sb + 1] + a.z * Uv[sb + 2];
+    const real u = tau - (a.x * Mx[8 * sb + 6] + a.y * Mx[8 * (sb + 1) + 6] + a.z * Mx[8 * (sb + 2) + 6]);
     const real Di = (real)1 / D;
-    st3(sh.AU[L], Ua); st3(sh.AU[L] + 3, Ul); sh.ADinv[L] = Di; sh.Au[L] = u;
+    w.par(6, [&](int i) { sh.AU[L][i] = Uv[i]; });
+    sh.ADinv[L] = Di; sh.Au[L] = u;
     if (p < 0) continue;   // arm root: parent is the fixed world
-    // I^a = I^A - U U^T / D
-    const V3 UaD = Di * Ua, UlD = Di * Ul;
-    A.xx -= UaD.x * Ua.x; A.yy -= UaD.y * Ua.y; A.zz -= UaD.z * Ua.z; A.xy -= UaD.x * Ua.y; A.xz -= UaD.x * Ua.z; A.yz -= UaD.y * Ua.z;
-    C.xx -= UlD.x * Ul.x; C.yy -= UlD.y * Ul.y; C.zz -= UlD.z * Ul.z; C.xy -= UlD.x * Ul.y; C.xz -= UlD.x * Ul.z; C.yz -= UlD.y * Ul.z;
-    B.m[0] -= UaD.x * Ul.x; B.m[1] -= UaD.x * Ul.y; B.m[2] -= UaD.x * Ul.z;
-    B.m[3] -= UaD.y * Ul.x; B.m[4] -= UaD.y * Ul.y; B.m[5] -= UaD.y * Ul.z;
-    B.m[6] -= UaD.z * Ul.x; B.m[7] -= UaD.z * Ul.y; B.m[8] -= UaD.z * Ul.z;
-    // p^a = p^A + I^a c + U u / D
-    const V3 ca = ld3(sh.a.CB[L]), cl = ld3(sh.a.CB[L] + 3);
     const real ud = u * Di;
-    const V3 qa = pa + mul(A, ca) + mul(B, cl) + ud * Ua;
-    const V3 ql = pl + tmul(B, ca) + mul(C, cl) + ud * Ul;
-    // translate to the parent's origin: r = o_L - o_p ;  B' = B + [r]x C ;  A' = A + [r]x B^T - B' [r]x  (symmetric)
-    const V3 r = ld3(sh.AR[L]);
-    M3 X;     // [r]x B^T : column j = r x (row j of B)
-    { V3 c0 = cross(r, mk(B.m[0], B.m[1], B.m[2])), c1 = cross(r, mk(B.m[3], B.m[4], B.m[5])), c2 = cross(r, mk(B.m[6], B.m[7], B.m[8]));
-      X.m[0] = c0.x; X.m[3] = c0.y; X.m[6] = c0.z; X.m[1] = c1.x; X.m[4] = c1.y; X.m[7] = c1.z; X.m[2] = c2.x; X.m[5] = c2.y; X.m[8] = c2.z; }
-    M3 Bn;    // B + [r]x C : column j of [r]x C = r x (column j of C)
-    { V3 c0 = cross(r, mk(C.xx, C.xy, C.xz)), c1 = cross(r, mk(C.xy, C.yy, C.yz)), c2 = cross(r, mk(C.xz, C.yz, C.zz));
-      Bn.m[0] = B.m[0] + c0.x; Bn.m[3] = B.m[3] + c0.y; Bn.m[6] = B.m[6] + c0.z; Bn.m[1] = B.m[1] + c1.x; Bn.m[4] = B.m[4] + c1.y; Bn.m[7] = B.m[7] + c1.z;
-      Bn.m[2] = B.m[2] + c2.x; Bn.m[5] = B.m[5] + c2.y; Bn.m[8] = B.m[8] + c2.z; }
-    // Y = B' [r]x : row i = (row i of B') x r
-    const V3 y0 = cross(mk(Bn.m[0], Bn.m[1], Bn.m[2]), r), y1 = cross(mk(Bn.m[3], Bn.m[4], Bn.m[5]), r), y2 = cross(mk(Bn.m[6], Bn.m[7], Bn.m[8]), r);
-    Acc T;
-    T.A.xx = A.xx + X.m[0] - y0.x; T.A.yy = A.yy + X.m[4] - y1.y; T.A.zz = A.zz + X.m[8] - y2.z;
-    T.A.xy = A.xy + (real)0.5 * ((X.m[1] - y0.y) + (X.m[3] - y1.x));
-    T.A.xz = A.xz + (real)0.5 * ((X.m[2] - y0.z) + (X.m[6] - y2.x));
-    T.A.yz = A.yz + (real)0.5 * ((X.m[5] - y1.z) + (X.m[7] - y2.y));
-    T.B = Bn; T.C = C;
-    T.pa = qa + cross(r, ql); T.pl = ql;
-    if (L == ANL - 1) hold = T;                                   // finger 8: park until finger 7 is done
-    else if (L == ANL - 2) {                                      // finger 7: both fingers feed link 6
-      carry = T;
-      carry.A.xx += hold.A.xx; carry.A.yy += hold.A.yy; carry.A.zz += hold.A.zz; carry.A.xy += hold.A.xy; carry.A.xz += hold.A.xz; carry.A.yz += hold.A.yz;
-      carry.C.xx += hold.C.xx; carry.C.yy += hold.C.yy; carry.C.zz += hold.C.zz; carry.C.xy += hold.C.xy; carry.C.xz += hold.C.xz; carry.C.yz += hold.C.yz;
-      for (int i = 0; i < 9; i++) carry.B.m[i] += hold.B.m[i];
-      carry.pa = carry.pa + hold.pa; carry.pl = carry.pl + hold.pl;
-    } else carry = T;
+    w.par(48, [&](int l) {
+      const int i = l >> 3, j = l & 7;
+      real v = 0;
+      if (j < 6) v = Mx[l] - Uv[i] * Uv[j] * Di;
+      else if (j == 6) {
+        real s1 = 0, s2 = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { const real ck = sh.a.CB[L][k]; s1 += Mx[8 * i + k] * ck; s2 += Uv[k] * ck; }
+        v = Mx[l] + s1 + Uv[i] * (ud - Di * s2);                       // p + (I^A - U U^T / D) c + U u / D
+      }
+      Cy[l] = v;
+    });
+    w.par(48, [&](int l) {
+      const int i = l >> 3, j = l & 7;
+      const int ia = i < 3 ? i : i - 3, ja = j < 3 ? j : j - 3;
+      const int i1 = ia == 2 ? 0 : ia + 1, i2 = ia == 0 ? 2 : ia - 1, j1 = ja == 2 ? 0 : ja + 1, j2 = ja == 0 ? 2 : ja - 1;
+      const real* r = sh.AR[L];
+      real v = Cy[l];
+      if (j < 6) {
+        if (i < 3 && j >= 3) v += r[i1] * Cy[8 * (3 + i2) + j] - r[i2] * Cy[8 * (3 + i1) + j];                    // B'[i][j-3]
+        else if (i >= 3 && j < 3) v += r[j1] * Cy[8 * (3 + j2) + i] - r[j2] * Cy[8 * (3 + j1) + i];               // B'[j][i-3] (C symmetric)
+        else if (i < 3 && j < 3) {
+          v += r[i1] * Cy[8 * j + 3 + i2] - r[i2] * Cy[8 * j + 3 + i1];                                           // ([r]x B^T)[i][j], B^T[k][j] = B[j][k]
+          const real b1 = Cy[8 * i + 3 + j1] + r[i1] * Cy[8 * (3 + i2) + 3 + j1] - r[i2] * Cy[8 * (3 + i1) + 3 + j1];   // B'[i][j1]
+          const real b2 = Cy[8 * i + 3 + j2] + r[i1] * Cy[8 * (3 + i2) + 3 + j2] - r[i2] * Cy[8 * (3 + i1) + 3 + j2];   // B'[i][j2]
+          v -= b1 * r[j2] - b2 * r[j1];                                                                          // (B' [r]x)[i][j]
+        }
+      } else if (j == 6 && i < 3) v += r[i1] * Cy[8 * (3 + i2) + 6] - r[i2] * Cy[8 * (3 + i1) + 6];               // p_a + r x p_l
+      if (L == ANL - 1) Hd[l] = v;                                    // finger 8: park until finger 7 is done
+      else if (L == ANL - 2) Mx[l] = v + Hd[l];                       // finger 7: both fingers feed link 6
+      else Mx[l] = v;
+    });
   }
   w.stamp(10);
   // outward sweep: accelerations (wave-uniform).  VW/VV are reused to carry (alpha, acc) of each link.
