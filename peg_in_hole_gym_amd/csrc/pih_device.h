@@ -681,6 +681,24 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
   sh.nc = nc; sh.nca = nca;
 }
 
+// ------------------------------------------------------------------------------------------------ cross-lane helpers
+#ifndef PIH_HOST_EMUL
+PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane must be wave-uniform): v_readlane_b32
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+template <int CTRL> PIH_HD real dpp_add(real x) {   // x + x[dpp-permuted lane]  (v_add_f32_dpp)
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+PIH_HD real sum8(real x) {               // sum over each aligned group of 8 lanes, result in all 8
+  x = dpp_add<0xB1>(x);                  // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);                  // quad_perm [2,3,0,1]
+  return dpp_add<0x141>(x);              // row_half_mirror
+}
+PIH_HD real from_lane(real v, int byte_addr) {   // v of lane byte_addr / 4 (per-lane source): ds_bpermute_b32, no LDS memory, no VALU slot
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ ABA
 // link velocities from the generalized velocity sh.u (wave-uniform serial sweep)
 PIH_HD void link_velocities(Shared& sh) {
@@ -754,43 +772,44 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
   real* const Mx = sh.r_lam; real* const Cy = sh.r_lam + 48; real* const Hd = sh.r_lam + 96; real* const Uv = sh.udot;
   static_assert(NROWC >= 144, "scratch of the inward sweep aliases r_lam");
   areal rootp[6] = {0, 0, 0, 0, 0, 0};
+  auto root_inverse = [&]() {
+    // root: invert the 6x6 articulated inertia held in Mx (order: angular, linear) by Gauss-Jordan (SPD), wave-uniform
+    areal Mq[6][6], Iv[6][6];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { Mq[i][j] = Mx[8 * i + j]; Iv[i][j] = i == j ? (areal)1 : (areal)0; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      areal pv = (areal)1 / Mq[k][k];
+#pragma unroll
+      for (int j = 0; j < 6; j++) { Mq[k][j] *= pv; Iv[k][j] *= pv; }
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (i != k) {
+        areal f = Mq[i][k];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { Mq[i][j] -= f * Mq[k][j]; Iv[i][j] -= f * Iv[k][j]; }
+      }
+    }
+    for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) sh.Inv6[6 * i + j] = (real)Iv[i][j]; rootp[i] = Mx[8 * i + 6]; }
+  };
+  // word of the packed record IAP[L] (A6 sym | B9 | C6 sym | p_a 3 | p_l 3 | 0) that holds entry (i, j)
+  auto own_word = [](int i, int j) {
+    const int ii = i < 3 ? i : i - 3, jj = j < 3 ? j : j - 3;
+    const int sym = ii == jj ? ii : ii + jj + 2;                      // xx yy zz xy xz yz
+    if (i >= 6 || j >= 7) return 27;
+    if (j == 6) return 21 + i;
+    if (i < 3 && j < 3) return sym;
+    if (i >= 3 && j >= 3) return 15 + sym;
+    if (i < 3) return 6 + 3 * i + jj;                                 // B[i][j-3]
+    return 6 + 3 * j + ii;                                            // B^T: B[j][i-3]
+  };
+#ifdef PIH_HOST_EMUL
   for (int L = NL - 1; L >= 0; L--) {
     const int p = L_PARENT[L], jt = L_JTYPE[L];
     const bool leaf = (L == NL - 1) || (L == ANL - 1) || (L == ANL - 2);
     w.par(48, [&](int l) {
-      const int i = l >> 3, j = l & 7;
-      // word of the packed record IAP[L] (A6 sym | B9 | C6 sym | p_a 3 | p_l 3 | 0) that holds entry (i, j)
-      const int ii = i < 3 ? i : i - 3, jj = j < 3 ? j : j - 3;
-      const int sym = ii == jj ? ii : ii + jj + 2;                    // xx yy zz xy xz yz
-      int off;
-      if (j >= 7) off = 27;
-      else if (j == 6) off = 21 + i;
-      else if (i < 3 && j < 3) off = sym;
-      else if (i >= 3 && j >= 3) off = 15 + sym;
-      else if (i < 3) off = 6 + 3 * i + jj;                           // B[i][j-3]
-      else off = 6 + 3 * j + ii;                                      // B^T: B[j][i-3]
-      const real own = sh.a.IAP[L][off];
+      const real own = sh.a.IAP[L][own_word(l >> 3, l & 7)];
       Mx[l] = leaf ? own : own + Mx[l];
     });
-    if (jt == PIH_JT_FLOATING) {
-      // root: invert the 6x6 articulated inertia (order: angular, linear) by Gauss-Jordan (SPD), wave-uniform
-      areal Mq[6][6], Iv[6][6];
-      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { Mq[i][j] = Mx[8 * i + j]; Iv[i][j] = i == j ? (areal)1 : (areal)0; }
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        areal pv = (areal)1 / Mq[k][k];
-#pragma unroll
-        for (int j = 0; j < 6; j++) { Mq[k][j] *= pv; Iv[k][j] *= pv; }
-#pragma unroll
-        for (int i = 0; i < 6; i++) if (i != k) {
-          areal f = Mq[i][k];
-#pragma unroll
-          for (int j = 0; j < 6; j++) { Mq[i][j] -= f * Mq[k][j]; Iv[i][j] -= f * Iv[k][j]; }
-        }
-      }
-      for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) sh.Inv6[6 * i + j] = (real)Iv[i][j]; rootp[i] = Mx[8 * i + 6]; }
-      continue;
-    }
+    if (jt == PIH_JT_FLOATING) { root_inverse(); continue; }
     const int sb = jt == PIH_JT_REVOLUTE ? 0 : 3;
     const V3 a = ld3(sh.LA[L]);
     w.par(6, [&](int i) { Uv[i] = Mx[8 * i + sb] * a.x + Mx[8 * i + sb + 1] * a.y + Mx[8 * i + sb + 2] * a.z; });
@@ -807,10 +826,9 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
       real v = 0;
       if (j < 6) v = Mx[l] - Uv[i] * Uv[j] * Di;
       else if (j == 6) {
-        real s1 = 0, s2 = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) { const real ck = sh.a.CB[L][k]; s1 += Mx[8 * i + k] * ck; s2 += Uv[k] * ck; }
-        v = Mx[l] + s1 + Uv[i] * (ud - Di * s2);                       // p + (I^A - U U^T / D) c + U u / D
+        real s1 = 0;
+        for (int k = 0; k < 6; k++) s1 += (Mx[8 * i + k] - Uv[i] * Uv[k] * Di) * sh.a.CB[L][k];
+        v = Mx[l] + s1 + Uv[i] * ud;                                   // p + I^a c + U u / D
       }
       Cy[l] = v;
     });
@@ -835,6 +853,69 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
       else Mx[l] = v;
     });
   }
+#else
+  // GPU form of the same four steps: the entry stays in a register of its lane; row sums are DPP reductions over the 8-lane
+  // row group, entries of other rows come through ds_bpermute (no LDS memory, no VALU slot), wave-uniform scalars (D, u, the
+  // U vector) through v_readlane.  The translation is branch-free: every lane evaluates
+  //     v + rA X1 - rB X2 - ( (X3 + rA X4 - rB X5) rG - (X6 + rA X7 - rB X8) rK )
+  // with per-lane source lanes and 0/1 masks fixed before the loop (B, B^T and p_a lanes use the first two terms only,
+  // C / p_l / idle lanes none), so one batch of 8 bpermutes and one wait serve the whole step.
+  {
+    (void)Cy; (void)Hd; (void)Uv;
+    const int l = w.lane(), i = l >> 3, j = l & 7;
+    const int ia = i < 3 ? i : (i < 6 ? i - 3 : 0), ja = j < 3 ? j : (j < 6 ? j - 3 : 0);
+    const int i1 = ia == 2 ? 0 : ia + 1, i2 = ia == 0 ? 2 : ia - 1, j1 = ja == 2 ? 0 : ja + 1, j2 = ja == 0 ? 2 : ja - 1;
+    const bool typeA = i < 3 && j < 3, typeB = i < 3 && j >= 3 && j < 6, typeBt = i >= 3 && i < 6 && j < 3, typeP = i < 3 && j == 6;
+    const int own_off = own_word(i, j);
+    // first pair of terms: coefficient indices into r and source lanes
+    int kA = 0, kB = 0, s1 = l, s2 = l;
+    if (typeA) { kA = i1; kB = i2; s1 = 8 * j + 3 + i2; s2 = 8 * j + 3 + i1; }
+    else if (typeB) { kA = i1; kB = i2; s1 = 8 * (3 + i2) + j; s2 = 8 * (3 + i1) + j; }
+    else if (typeBt) { kA = j1; kB = j2; s1 = 8 * (3 + j2) + i; s2 = 8 * (3 + j1) + i; }
+    else if (typeP) { kA = i1; kB = i2; s1 = 8 * (3 + i2) + 6; s2 = 8 * (3 + i1) + 6; }
+    const real m1 = (typeA || typeB || typeBt || typeP) ? (real)1 : (real)0, m2 = typeA ? (real)1 : (real)0;
+    int s3 = l, s4 = l, s5 = l, s6 = l, s7 = l, s8 = l;
+    if (typeA) { s3 = 8 * i + 3 + j1; s4 = 8 * (3 + i2) + 3 + j1; s5 = 8 * (3 + i1) + 3 + j1; s6 = 8 * i + 3 + j2; s7 = 8 * (3 + i2) + 3 + j2; s8 = 8 * (3 + i1) + 3 + j2; }
+    const int sUj = j < 6 ? 8 * j : l;                                 // any lane of row j holds U_j
+    real carry = 0, hold = 0;
+    for (int L = NL - 1; L >= 0; L--) {
+      const int p = L_PARENT[L], jt = L_JTYPE[L];
+      const bool leaf = (L == NL - 1) || (L == ANL - 1) || (L == ANL - 2);
+      const real own = sh.a.IAP[L][own_off];
+      const real m = leaf ? own : own + carry;
+      if (jt == PIH_JT_FLOATING) {
+        w.sync(); if (l < 48) Mx[l] = m; w.sync();
+        root_inverse();
+        continue;
+      }
+      const int sb = jt == PIH_JT_REVOLUTE ? 0 : 3;
+      const V3 a = ld3(sh.LA[L]);
+      const real rA = m1 * sh.AR[L][kA], rB = m1 * sh.AR[L][kB], rG = m2 * sh.AR[L][j2], rK = m2 * sh.AR[L][j1];
+      const real cj = j < 6 ? sh.a.CB[L][j] : (real)0;
+      const int js = j - sb;
+      const real sj = js == 0 ? a.x : (js == 1 ? a.y : (js == 2 ? a.z : (real)0));
+      const real Ui = sum8(m * sj);                                    // U_i = sum_k I^A[i][sb + k] a_k, in every lane of row i
+      const real Uj = from_lane(Ui, 4 * sUj);
+      const real D = a.x * rdlane(Ui, 8 * sb) + a.y * rdlane(Ui, 8 * (sb + 1)) + a.z * rdlane(Ui, 8 * (sb + 2));
+      const real tau = -L_DAMPING[L] * sh.u[link_dof(L)];
+      const real u = tau - (a.x * rdlane(m, 8 * sb + 6) + a.y * rdlane(m, 8 * (sb + 1) + 6) + a.z * rdlane(m, 8 * (sb + 2) + 6));
+      const real Di = (real)1 / D;
+      if (j == 0 && i < 6) sh.AU[L][i] = Ui;
+      if (l == 0) { sh.ADinv[L] = Di; sh.Au[L] = u; }
+      if (p < 0) continue;   // arm root: parent is the fixed world
+      real ma = j < 6 ? m - Ui * Uj * Di : m;                          // I^a ; column 6 is fixed up next
+      const real s = sum8(j < 6 ? ma * cj : (real)0);                  // (I^a c)_i in every lane of row i
+      if (j == 6) ma = m + s + Ui * (u * Di);                          // p^a = p^A + I^a c + U u / D
+      const real X1 = from_lane(ma, 4 * s1), X2 = from_lane(ma, 4 * s2), X3 = from_lane(ma, 4 * s3), X4 = from_lane(ma, 4 * s4),
+                 X5 = from_lane(ma, 4 * s5), X6 = from_lane(ma, 4 * s6), X7 = from_lane(ma, 4 * s7), X8 = from_lane(ma, 4 * s8);
+      const real v = ma + rA * X1 - rB * X2 - ((X3 + rA * X4 - rB * X5) * rG - (X6 + rA * X7 - rB * X8) * rK);
+      if (L == ANL - 1) hold = v;                                      // finger 8: park until finger 7 is done
+      else if (L == ANL - 2) carry = v + hold;                         // finger 7: both fingers feed link 6
+      else carry = v;
+    }
+    w.sync();
+  }
+#endif
   w.stamp(10);
   // outward sweep: accelerations (wave-uniform).  VW/VV are reused to carry (alpha, acc) of each link.
   {
@@ -1083,12 +1164,6 @@ PIH_HD real jac_entry(const DofGeom& g, int la, int lb, V3 p, V3 dir) {
 #ifdef PIH_HOST_EMUL
 template <class F> inline real wave_sum(Wave&, int n, F f) { real s = 0; for (int i = 0; i < n; i++) s += f(i); return s; }
 #else
-PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane must be wave-uniform): v_readlane_b32
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-template <int CTRL> PIH_HD real dpp_add(real x) {   // x + x[dpp-permuted lane]  (v_add_f32_dpp)
-  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
-}
 // after row16_sum3: rows 1,3 += lane 15 of the previous row (row_bcast:15), rows 2,3 += lane 31 (row_bcast:31)
 // => lanes 32..47 hold the sum over lanes 0..47 (all 38 DOF lanes).  Written as inline asm because hipcc lowers the
 // masked-row form to v_mov 0 + v_mov_dpp + v_add (3 instructions) instead of one fused v_add_f32_dpp; the s_nop covers the
