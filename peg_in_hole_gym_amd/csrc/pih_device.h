@@ -701,7 +701,7 @@ PIH_HD real from_lane(real v, int byte_addr) {   // v of lane byte_addr / 4 (per
 
 // ------------------------------------------------------------------------------------------------ ABA
 // link velocities from the generalized velocity sh.u (wave-uniform serial sweep)
-PIH_HD void link_velocities(Shared& sh) {
+PIH_HD void link_velocities_serial(Shared& sh) {
   V3 wp = mk(0, 0, 0), vp = mk(0, 0, 0), op = mk(0, 0, 0), w6 = wp, v6 = vp, o6 = op;   // parent's twist / origin, in registers
   for (int L = 0; L < NL; L++) {
     int jt = L_JTYPE[L], d = link_dof(L);
@@ -719,12 +719,58 @@ PIH_HD void link_velocities(Shared& sh) {
     if (L == ANL - 3) { w6 = wv; v6 = vv; o6 = o; }
   }
 }
+#ifndef PIH_HOST_EMUL
+// The same recurrences as two inclusive prefix sums along the chains (lane = link): omega_L = sum over the path of the joint
+// angular rates, v_L = sum over the path of (omega_parent x (o_L - o_parent) + prismatic rate).  Hillis-Steele steps through
+// ds_bpermute (5 steps cover the 24-link pipe); finger 8 is a child of link 6, not of finger 7, so it drops finger 7's terms.
+PIH_HD V3 from_lane3(V3 v, int byte_addr) { return mk(from_lane(v.x, byte_addr), from_lane(v.y, byte_addr), from_lane(v.z, byte_addr)); }
+PIH_HD V3 chain_prefix_sum(V3 t, int lane, int chain_start) {
+  V3 acc = t;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const int src = lane - off;
+    const V3 o = from_lane3(acc, 4 * (src < 0 ? 0 : src));
+    if (src >= chain_start) acc = acc + o;
+  }
+  return acc;
+}
+PIH_HD void link_velocities_scan(Shared& sh, int lane) {
+  const bool active = lane < NL;
+  const int L = active ? lane : NL - 1;
+  const int jt = L == ANL ? PIH_JT_FLOATING : ((L == ANL - 1 || L == ANL - 2) ? PIH_JT_PRISMATIC : PIH_JT_REVOLUTE);
+  const int par = (L == 0 || L == ANL) ? -1 : (L == ANL - 1 ? ANL - 3 : L - 1);
+  const int cs = L < ANL ? 0 : ANL, d = link_dof(L);
+  const V3 aq = sh.u[d] * ld3(sh.LA[L]);
+  const V3 tw = jt == PIH_JT_FLOATING ? ld3(&sh.u[d + 3]) : (jt == PIH_JT_REVOLUTE ? aq : mk(0, 0, 0));
+  V3 wv = chain_prefix_sum(tw, lane, cs);
+  const V3 tw7 = from_lane3(tw, 4 * (ANL - 2));
+  if (L == ANL - 1) wv = wv - tw7;
+  const V3 wp = from_lane3(wv, 4 * (par < 0 ? 0 : par));
+  V3 tv;
+  if (jt == PIH_JT_FLOATING) tv = ld3(&sh.u[d]);
+  else {
+    tv = jt == PIH_JT_PRISMATIC ? aq : mk(0, 0, 0);
+    if (par >= 0) tv = tv + cross(wp, ld3(sh.LO[L]) - ld3(sh.LO[par]));
+  }
+  V3 vv = chain_prefix_sum(tv, lane, cs);
+  const V3 tv7 = from_lane3(tv, 4 * (ANL - 2));
+  if (L == ANL - 1) vv = vv - tv7;
+  if (active) { st3(sh.VW[L], wv); st3(sh.VV[L], vv); }
+}
+#endif
+template <class W> PIH_HD void link_velocities(W& w, Shared& sh) {
+#ifdef PIH_HOST_EMUL
+  (void)w; link_velocities_serial(sh);
+#else
+  w.sync(); link_velocities_scan(sh, w.lane()); w.sync();
+#endif
+}
 
 // Articulated-body algorithm; leaves U, 1/D, r per link and the inverse root inertia for the impulse responses,
 // and the free acceleration in sh.udot.
 template <class W> PIH_HD void aba(W& w, Shared& sh) {
   w.stamp(15);
-  link_velocities(sh);
+  link_velocities(w, sh);
   w.stamp(8);
   // per-link spatial inertia about the link origin, velocity-product acceleration and bias force (lane = link)
   w.par(NL, [&](int L) {
@@ -1042,7 +1088,7 @@ struct MotorW { real w[PIH_OBJ_NJ]; };
 template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, const Ovf& ov, MotorW& mw) {
   const real dt = P.dt;
   // link velocities after the free update (contact / motor right-hand sides)
-  link_velocities(sh);
+  link_velocities(w, sh);
   // Response rows (lane = row): global row g < 32 is a motor row (unit joint impulse; the limit rows share its W and
   // 1/(J W)), row 32 + 3c + k is row k of contact c (k = 0 normal, 1/2 friction directions).  ONE call site of response()
   // serves both kinds with per-lane arguments, and the first pass takes the 32 motor rows together with the first 9 contacts

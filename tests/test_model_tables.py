@@ -65,3 +65,19 @@ def test_ur5_tables_match_ur5_urdf(T):
         np.testing.assert_allclose(R[i].reshape(3, 3), T.rpy_matrix(*rpy), atol=1e-15)
     np.testing.assert_allclose(_macro("PIH_UR5_EE_R").reshape(3, 3), T.rpy_matrix(*u["ee_rpy"]), atol=1e-15)
     assert u["rpy"][0][2] == 3.14 and u["rpy"][1][1] == 1.6 and u["damping"] == [0.5] * 6       # the literal 3.14 / 1.6 of the file
+
+
+def test_link_tree_shape_assumed_by_the_lane_parallel_sweeps():
+    """pih_device.h derives joint type and parent of link L arithmetically in its lane-parallel paths (link_velocities_scan,
+    response): arm 0-6 revolute chain, fingers 7/8 prismatic children of link 6, link 9 floating root, 10-32 revolute chain."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "pih_model.h")).read()
+    def arr(name):
+        m = re.search(r"#define %s \{([^}]*)\}" % name, hdr)
+        return [int(x) for x in m.group(1).split(",")]
+    jt, par = arr("PIH_LINK_JTYPE"), arr("PIH_LINK_PARENT")
+    REV, PRI = 0, 1
+    FLO = int(re.search(r"#define PIH_JT_FLOATING (\d+)", hdr).group(1))
+    assert len(jt) == 33 and len(par) == 33
+    assert jt[:7] == [REV] * 7 and jt[7:9] == [PRI] * 2 and jt[9] == FLO and jt[10:] == [REV] * 23
+    assert par[:9] == [-1, 0, 1, 2, 3, 4, 5, 6, 6] and par[9] == -1 and par[10:] == list(range(9, 32))
