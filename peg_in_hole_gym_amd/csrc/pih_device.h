@@ -202,6 +202,24 @@ struct Wave {
 };
 #endif
 
+// ------------------------------------------------------------------------------------------------ cross-lane helpers
+#ifndef PIH_HOST_EMUL
+PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane must be wave-uniform): v_readlane_b32
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+template <int CTRL> PIH_HD real dpp_add(real x) {   // x + x[dpp-permuted lane]  (v_add_f32_dpp)
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+PIH_HD real sum8(real x) {               // sum over each aligned group of 8 lanes, result in all 8
+  x = dpp_add<0xB1>(x);                  // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);                  // quad_perm [2,3,0,1]
+  return dpp_add<0x141>(x);              // row_half_mirror
+}
+PIH_HD real from_lane(real v, int byte_addr) {   // v of lane byte_addr / 4 (per-lane source): ds_bpermute_b32, no LDS memory, no VALU slot
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ kinematics
 // local transform of link L for joint value q (lane = link)
 PIH_HD void local_transform(int L, real q, const real* S, real* T) {
@@ -216,7 +234,7 @@ PIH_HD void local_transform(int L, real q, const real* S, real* T) {
   else { stm(T, Rf); st3(T + 9, t + q * mul(Rf, ax)); }
 }
 
-template <class W> PIH_HD void fk_all(W& w, Shared& sh) {
+template <class W> PIH_HD void fk_all_serial(W& w, Shared& sh) {
   w.par(NL, [&](int L) {
     real q = L < ANL ? sh.S[PIH_S_QARM + L] : (L == ANL ? (real)0 : sh.S[PIH_S_QJ + L - ANL - 1]);
     local_transform(L, q, sh.S, sh.a.Tl[L]);
@@ -244,6 +262,54 @@ template <class W> PIH_HD void fk_all(W& w, Shared& sh) {
     st3(sh.a.LRC[L], mul(R, ld3(L_COM[L])));
     sts3(sh.a.LIC[L], rot_sym(R, lds3(L_INERTIA[L])));
   });
+}
+#ifndef PIH_HOST_EMUL
+// GPU form: lane = link.  The world pose of a link is the product of the local transforms along its chain, i.e. an inclusive
+// prefix "product" of rigid transforms: five Hillis-Steele steps (12 ds_bpermute + 39 FMA each) instead of a 33-link serial
+// composition, and the pose never leaves the lane's registers before the world axes / rotated inertias are written.
+// Out-of-chain sources read lane 63, which holds the identity.  Finger 8 is a child of link 6, not of finger 7: it takes
+// finger 7's position in the chain order.  The arm's base rotation is folded into link 0's local transform.
+PIH_HD int lane_byte(int lane) { return 4 * lane; }
+template <class W> PIH_HD void fk_all_scan(W& w, Shared& sh) {
+  w.sync();
+  const int lane = w.lane();
+  const bool active = lane < NL;
+  const int L = active ? lane : NL - 1;
+  M3 R = ldm(IDENT3); V3 o = mk(0, 0, 0);
+  if (active) {
+    real T[12];
+    const real q = L < ANL ? sh.S[PIH_S_QARM + L] : (L == ANL ? (real)0 : sh.S[PIH_S_QJ + L - ANL - 1]);
+    local_transform(L, q, sh.S, T);
+    R = ldm(T); o = ld3(T + 9);
+    if (L == 0) { const M3 B = ldm(ARM_BASE_R); o = mul(B, o); R = mul(B, R); }
+  }
+  const int cs = L < ANL ? 0 : ANL;
+  const int vidx = L == ANL - 1 ? ANL - 2 : lane;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const int src = vidx - off;
+    const int sb = lane_byte((active && src >= cs) ? src : 63);
+    M3 Rs; V3 os;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rs.m[k] = from_lane(R.m[k], sb);
+    os = mk(from_lane(o.x, sb), from_lane(o.y, sb), from_lane(o.z, sb));
+    o = os + mul(Rs, o); R = mul(Rs, R);
+  }
+  if (active) {
+    stm(sh.a.LR[L], R); st3(sh.LO[L], o);
+    st3(sh.LA[L], mul(R, ld3(L_AXIS[L])));
+    st3(sh.a.LRC[L], mul(R, ld3(L_COM[L])));
+    sts3(sh.a.LIC[L], rot_sym(R, lds3(L_INERTIA[L])));
+  }
+  w.sync();
+}
+#endif
+template <class W> PIH_HD void fk_all(W& w, Shared& sh) {
+#ifdef PIH_HOST_EMUL
+  fk_all_serial(w, sh);
+#else
+  fk_all_scan(w, sh);
+#endif
 }
 PIH_HD void ee_pose(const Shared& sh, V3& p, M3& R) {
   M3 Rp = ldm(sh.a.LR[PIH_EE_PARENT]);
@@ -680,24 +746,6 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
   int nc = w.alloc_count(); if (nc > CMAX) nc = CMAX;
   sh.nc = nc; sh.nca = nca;
 }
-
-// ------------------------------------------------------------------------------------------------ cross-lane helpers
-#ifndef PIH_HOST_EMUL
-PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane must be wave-uniform): v_readlane_b32
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-template <int CTRL> PIH_HD real dpp_add(real x) {   // x + x[dpp-permuted lane]  (v_add_f32_dpp)
-  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
-}
-PIH_HD real sum8(real x) {               // sum over each aligned group of 8 lanes, result in all 8
-  x = dpp_add<0xB1>(x);                  // quad_perm [1,0,3,2]
-  x = dpp_add<0x4E>(x);                  // quad_perm [2,3,0,1]
-  return dpp_add<0x141>(x);              // row_half_mirror
-}
-PIH_HD real from_lane(real v, int byte_addr) {   // v of lane byte_addr / 4 (per-lane source): ds_bpermute_b32, no LDS memory, no VALU slot
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------ ABA
 // link velocities from the generalized velocity sh.u (wave-uniform serial sweep)
