@@ -1464,6 +1464,9 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       const real sdu = (real)(int)__builtin_amdgcn_sbfe(sgw, 2u * (unsigned)(c & 15), 2u) * du;
       const V3 cv = mk(__builtin_fmaf(ae.y, pr.z, __builtin_fmaf(-ae.z, pr.y, mp.x)), __builtin_fmaf(ae.z, pr.x, __builtin_fmaf(-ae.x, pr.z, mp.y)), __builtin_fmaf(ae.x, pr.y, __builtin_fmaf(-ae.y, pr.x, mp.z)));
       real jd0 = sdu * dot(mk(r.q[2].x, r.q[2].y, r.q[2].z), cv), jd1 = sdu * dot(mk(r.q[3].x, r.q[3].y, r.q[3].z), cv), jd2 = sdu * dot(mk(r.q[4].x, r.q[4].y, r.q[4].z), cv);
+      // materialise the products: otherwise fast-math folds the multiply into the first reduction step as mul + mov_dpp + fmac
+      // (3 instructions per value) instead of mul + v_add_f32_dpp (2)
+      __asm__ volatile("" : "+v"(jd0), "+v"(jd1), "+v"(jd2));
       row16_sum3(jd0, jd1, jd2);
       rows012_total3(jd0, jd1, jd2);          // valid in lanes 32..47 from here; the scalar chain below runs in plain VGPRs
       const real l0 = r.q[6].z, l1 = r.q[6].w, l2 = r.q[7].x;
