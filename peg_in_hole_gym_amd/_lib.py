@@ -45,6 +45,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PihError("HIP extension %s is missing: build it with `python peg_in_hole_gym_amd/csrc/build.py` "
                        "(there is no CPU fallback)" % LIB_PATH)
+    # torch must be in the process BEFORE libpih_hip.so: both link libamdhip64, and the process has to end up with ONE HIP
+    # runtime (the one torch ships) -- loaded the other way round, pih_create sees no device
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.pih_default_config.argtypes = [C.POINTER(PihConfig)]

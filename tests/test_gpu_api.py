@@ -80,3 +80,14 @@ def test_timing_api_and_obs_fields(torch_mod):
     assert torch.allclose(obs[:, 2:5], g.ee_position()) and torch.allclose(obs[:, 0:2], st[:, 7:9])
     assert torch.equal(g.tip_pose(), st[:, 98:105]) and torch.equal(g.contact_force(), st[:, 105])
     assert ((rew == 0) | (rew == 1)).all() and ((done == 0) | (done == 1)).all()
+
+
+def test_graft_entry_build_then_smoke_in_a_fresh_process():
+    """The driver calls build() and smoke() in one fresh interpreter: the HIP library must not be loaded before torch
+    (two HIP runtimes in one process -> pih_create sees no device)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "smoke ok" in out.stdout
