@@ -111,7 +111,9 @@ PIH_HD int link_dof(int L) { return L < ANL ? L : (L == ANL ? 9 : L + 5); }
 // LDS is time-multiplexed: the kinematics / ABA scratch (arena A) is dead once the free velocity update is done, the
 // solver scratch (arena B) is dead once the PGS result has been folded into the velocities.
 struct ArenaA {
-  real Tl[NL][12];                 // local (parent->link) transforms
+#ifdef PIH_HOST_EMUL
+  real Tl[NL][12];                 // local (parent->link) transforms (the GPU keeps them in registers: fk_all_scan)
+#endif
   real LR[NL][9], LRC[NL][3], LIC[NL][6];   // world rotation, com offset, inertia about com (world axes)
   alignas(16) real IAP[NL][28];   // per link: own spatial inertia about the link origin (A6 B9 C6) + bias force (6) + pad
   real CB[NL][6];                  // velocity-product accelerations, then (alpha, acc) of each link
@@ -234,6 +236,7 @@ PIH_HD void local_transform(int L, real q, const real* S, real* T) {
   else { stm(T, Rf); st3(T + 9, t + q * mul(Rf, ax)); }
 }
 
+#ifdef PIH_HOST_EMUL
 template <class W> PIH_HD void fk_all_serial(W& w, Shared& sh) {
   w.par(NL, [&](int L) {
     real q = L < ANL ? sh.S[PIH_S_QARM + L] : (L == ANL ? (real)0 : sh.S[PIH_S_QJ + L - ANL - 1]);
@@ -263,6 +266,7 @@ template <class W> PIH_HD void fk_all_serial(W& w, Shared& sh) {
     sts3(sh.a.LIC[L], rot_sym(R, lds3(L_INERTIA[L])));
   });
 }
+#endif
 #ifndef PIH_HOST_EMUL
 // GPU form: lane = link.  The world pose of a link is the product of the local transforms along its chain, i.e. an inclusive
 // prefix "product" of rigid transforms: five Hillis-Steele steps (12 ds_bpermute + 39 FMA each) instead of a 33-link serial
