@@ -223,3 +223,27 @@ def test_scripted_mode_on_gpu(torch_mod, oracle_mod):
     errs = np.concatenate(errs)
     print("scripted one-step pose err p50/p99/max = %.2e / %.2e / %.2e" % (np.percentile(errs, 50), np.percentile(errs, 99), errs.max()))
     assert np.percentile(errs, 50) < 5e-6 and np.percentile(errs, 99) < 5e-4
+
+
+def test_arm_table_contact_on_gpu(torch_mod, oracle_mod):
+    """Arm collision spheres vs the table (keys 3000+, linkA = arm link, no pipe response): drive the gripper into the table,
+    GPU resynchronised to the oracle before every step.  Same contact sets, arm stops at the table, small one-step errors."""
+    torch = torch_mod
+    N = 8
+    kw = dict(residual_threshold=0.0, warmstart=0.0)
+    o = oracle_mod.Oracle(N, **kw); g = _gpu(N, **kw)
+    p0, _ = oracle_mod.fk_arm(REST, 9)
+    a = np.tile([p0[0] + 0.25, p0[1] - 0.25, -1.0, 0.04], (N, 1))
+    seen = 0; perr = []; lowest = 1.0
+    for t in range(420):
+        _to_gpu_state(torch, g, o.get_state())
+        o.step(a); g.step(torch.tensor(a, dtype=torch.float32))
+        so = o.get_state(); sg = g.state().cpu().numpy().astype(np.float64)
+        np.testing.assert_array_equal(o.ncontacts(), sg[:, 106].astype(int))
+        seen += any(int(k) >= 3000 for k in o.debug_contacts(0)[:, 10])
+        perr.append(np.abs(so[:, POS] - sg[:, POS]).max(1))
+        lowest = min(lowest, oracle_mod.fk_arm(so[0, 0:9], 9)[0][2])
+    perr = np.concatenate(perr)
+    print("arm-table one-step pose err p50/p99/max = %.2e / %.2e / %.2e" % (np.percentile(perr, 50), np.percentile(perr, 99), perr.max()))
+    assert seen > 50 and lowest > -0.05 - 0.004
+    assert np.percentile(perr, 50) < 5e-6 and np.percentile(perr, 99) < 1e-4
