@@ -1406,7 +1406,7 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
     __asm__ volatile("" ::: "memory");
     // row constants come from LDS as 16-byte broadcasts, explicitly prefetched PF records ahead: the dependent chain of one
     // motor step is ~6 VALU ops (~50 cycles) while an LDS round trip is >100, so a distance-1 prefetch stalls every step
-    constexpr int PF = 4;
+    constexpr int PF = 6;
     real4 pm[PF], pa4[PF], pl4[PF];
 #pragma unroll
     for (int k = 0; k < PF; k++) { pm[k] = *reinterpret_cast<const real4*>(sh.mrec[9 + k]); pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
