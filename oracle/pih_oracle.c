@@ -1001,10 +1001,12 @@ void piho_render(const piho_handle* h, int W, int H, double* out /* [n,H,W,4] */
         double xc = (2.0 * (j + 0.5) / W - 1.0) * tanh2, yc = (1.0 - 2.0 * (i + 0.5) / H) * tanh2;   /* aspect 1 */
         v3 d = {xc, yc, -1.0}; double dn = v_norm(d); d[0] /= dn; d[1] /= dn; d[2] /= dn;
         double best = 1e30, col = 255.0;
-        if (d[2] < 0) { double t = (PIH_TABLE_Z - eye[2]) / d[2]; if (t > 0 && t < best) { best = t; col = 153.0; } }
-        for (int sg = 0; sg < 24; sg++) { double t = ray_capsule(eye, d, vtx[sg], vtx[sg + 1], PIH_PIPE_RADIUS); if (t < best) { best = t; col = 232.0; } }
-        { double t = ray_tube(eye, d); if (t < best) { best = t; col = 232.0; } }
-        for (int f = 0; f < 2; f++) { double t = ray_box(eye, d, K[PIH_FINGER_LINK0 + f].R, fc[f], FBOX_H); if (t < best) { best = t; col = 77.0; } }
+        const double tnear = nearv * dn;   /* ray parameter of the near plane: fragments in front of it are clipped (with closed
+                                              fingers the eye lies ON the pad faces) */
+        if (d[2] < 0) { double t = (PIH_TABLE_Z - eye[2]) / d[2]; if (t >= tnear && t < best) { best = t; col = 153.0; } }
+        for (int sg = 0; sg < 24; sg++) { double t = ray_capsule(eye, d, vtx[sg], vtx[sg + 1], PIH_PIPE_RADIUS); if (t < best && t >= tnear) { best = t; col = 232.0; } }
+        { double t = ray_tube(eye, d); if (t < best && t >= tnear) { best = t; col = 232.0; } }
+        for (int f = 0; f < 2; f++) { double t = ray_box(eye, d, K[PIH_FINGER_LINK0 + f].R, fc[f], FBOX_H); if (t < best && t >= tnear) { best = t; col = 77.0; } }
         double depth = 1.0;
         if (best < 1e29) { double z = best / dn; depth = farv * (z - nearv) / (z * (farv - nearv)); }   /* z = distance along the view axis */
         double* px = img + ((size_t)i * W + j) * 4;

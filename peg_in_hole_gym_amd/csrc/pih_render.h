@@ -170,24 +170,26 @@ PIH_HD real4 shade(const Scene& sc, unsigned prims, real xc, real yc) {
   real inv = rsqrt_((real)1 + xc * xc + yc * yc);
   V3 d = mk(xc * inv, yc * inv, -inv);
   real best = PIH_BIG, col = PIH_COL_BG;
+  const real tnear = PIH_CAM_NEAR / inv;   // ray parameter of the near plane: fragments in front of it are clipped (with closed
+                                           // fingers the eye lies ON the pad faces: their hits at t ~ 0 must not be drawn)
   {
     real t = (PIH_TABLE_Z - eye.z) / d.z;
-    if (t > 0) { best = t; col = PIH_COL_TABLE; }
+    if (t >= tnear) { best = t; col = PIH_COL_TABLE; }
   }
   unsigned segs = prims & ((1u << NSEG) - 1u);
   while (segs) {
     const int sidx = __builtin_ctz(segs); segs &= segs - 1u;
     real t = ray_capsule(eye, d, ld3(sc.vtx[sidx]), ld3(sc.vtx[sidx + 1]), PIH_PIPE_RADIUS);
-    if (t < best) { best = t; col = PIH_COL_PIPE; }
+    if (t < best && t >= tnear) { best = t; col = PIH_COL_PIPE; }
   }
   if (prims & (1u << (NSEG + 2))) {
     real t = ray_tube(eye, d);
-    if (t < best) { best = t; col = PIH_COL_PIPE; }
+    if (t < best && t >= tnear) { best = t; col = PIH_COL_PIPE; }
   }
   for (int f = 0; f < 2; f++)
     if (prims & (1u << (NSEG + f))) {
       real t = ray_box(eye, d, ldm(sc.fR[f]), ld3(sc.fc[f]), ld3(FBOX_H));
-      if (t < best) { best = t; col = PIH_COL_FINGER; }
+      if (t < best && t >= tnear) { best = t; col = PIH_COL_FINGER; }
     }
   real depth = 1;
   if (best < (real)1e29) {

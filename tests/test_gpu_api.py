@@ -91,3 +91,25 @@ def test_graft_entry_build_then_smoke_in_a_fresh_process():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "smoke ok" in out.stdout
+
+
+def test_integration_md_ctypes_stub_runs_as_written(torch_mod):
+    """INTEGRATION.md section 1 is the binding a maintainer of the reference would add: execute that code block verbatim
+    (only the library name is made absolute) with the free variables a caller would own, and check that it did step."""
+    import os, re
+    torch = torch_mod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# peg_in_hole_gym/envs/_pih\.py.*?)```", md, re.S).group(1)
+    code = code.replace('"libpih_hip.so"', repr(os.path.join(root, "peg_in_hole_gym_amd", "csrc", "libpih_hip.so")))
+    n = 6
+    ns = dict(mp_num=2, sub_num=3, offsets_host_ptr=None, hard_reset=False,
+              actions=torch.zeros(n, 4, device="cuda"), obs=torch.full((n, 5), -7.0, device="cuda"),
+              reward=torch.zeros(n, device="cuda"), done=torch.zeros(n, dtype=torch.uint8, device="cuda"),
+              img=torch.zeros(n, 300, 300, 4, device="cuda"))
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    torch.cuda.synchronize()
+    assert ns["cfg"].n_envs == n and ns["cfg"].solver_iters == 50
+    assert (ns["obs"] != -7.0).all() and torch.isfinite(ns["obs"]).all()          # pih_step wrote the observations
+    assert 0.0 < float(ns["img"][..., 0].min()) <= float(ns["img"][..., 0].max()) <= 1.0   # pih_render wrote a depth buffer (near..far)
+    assert ns["L"].pih_destroy(ns["h"]) == 0

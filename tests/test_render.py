@@ -29,9 +29,14 @@ def test_depth_of_bare_table_is_the_closed_form(oracle_mod):
     # beside the eye, outside the 60 degree cone
     assert np.allclose(img[:, :, 0], gl_depth(ee[2] - TABLE_Z), atol=1e-12)
     assert (img[:, :, 1:] == 153.0).all()
-    # at the rest pose the hand is tilted and a finger pad covers part of the straight-down view
+    # near-plane clipping: at the rest pose the fingers are closed and the eye (the grasp target) lies ON the faces of both
+    # pads; their hits at ray parameter ~0 are in front of the near plane and must not be drawn (they gave depth << 0)
     o2 = O.Oracle(1)
-    assert set(np.unique(o2.render(40, 30)[0][:, :, 1])) >= {153.0, 77.0}
+    s2 = o2.get_state(); s2[0, 18] = 5.0; o2.set_state(s2)
+    img2 = o2.render(40, 30)[0]
+    assert (img2[:, :, 0] > 0.9).all() and (img2[:, :, 0] <= 1.0).all()
+    ee2 = O.fk_arm(s2[0, 0:9], 9)[0]
+    assert np.allclose(img2[:, :, 0], gl_depth(ee2[2] - TABLE_Z), atol=1e-12) and (img2[:, :, 1] == 153.0).all()
 
 
 def test_pipe_silhouette_and_depth_bounds(oracle_mod):
@@ -94,6 +99,12 @@ def test_hip_render_matches_oracle():
         za = NEAR * FAR / (FAR - a[..., 0].astype(np.float64) * (FAR - NEAR)); zb = NEAR * FAR / (FAR - b[..., 0] * (FAR - NEAR))
         assert np.percentile(np.abs(za - zb)[same], 99) < 2e-4      # metres (fp32 resolution of 1 - near/z at z ~ 0.3 m)
         assert (a[..., 1] == 232.0).any()
+    # rest pose (fingers closed: the eye lies on the pad faces, their t ~ 0 hits are clipped by the near plane)
+    g0 = PihVecEnv(3, seed=7); o0 = O.Oracle(3, seed=7)
+    o0.set_state(g0.state().cpu().numpy()[:, :128].astype(np.float64))
+    a0 = g0.render(64, 48).cpu().numpy(); b0 = o0.render(64, 48)
+    assert (a0[..., 0] > 0.9).all() and (a0[..., 0] <= 1.0).all()
+    assert (a0[..., 1] == b0[..., 1]).mean() > 0.997 and np.abs(a0[..., 0] - b0[..., 0])[a0[..., 1] == b0[..., 1]].max() < 2e-6
     # a sub-range of envs renders the same pixels
     part = g.render(97, 61, env_begin=2, env_count=3).cpu().numpy()
     assert np.array_equal(part, g.render(97, 61).cpu().numpy()[2:5])
