@@ -150,3 +150,22 @@ def test_scripted_facade_on_gpu(torch_mod):
     env.render()
     assert env.images[1][1].shape == (300, 300, 4)
     env.close()
+
+
+def test_integration_md_drop_in_usage_on_gpu(torch_mod):
+    """INTEGRATION.md section 3 (smaller batch) and the single-process path of section 4 on the real backend."""
+    import peg_in_hole_gym_amd as peg_in_hole_gym
+    env = peg_in_hole_gym.make('peg-in-hole-mp-v0', client=None, task='peg-in-hole', mp_num=4, sub_num=4,
+                               offset=[2., 3., 0.], args=None, is_test=False)
+    obs = env.reset()
+    assert len(obs) == 4 and len(obs[0]) == 4 and obs[0][0].shape == (5,)
+    for _ in range(3):
+        obs, reward, done, info = env.step(env.action_space.sample())
+    assert len(reward) == 4 and len(done[3]) == 4 and np.isfinite(np.asarray(obs)).all()
+    o2, r2, d2 = env.step_tensor(torch_mod.zeros(16, 4, device="cuda"))
+    assert o2.shape == (16, 5) and o2.is_cuda
+    env.close()
+    from peg_in_hole_gym_amd.distributed import ShardedVecEnv
+    sv = ShardedVecEnv(total_envs=128, gather_obs=True)
+    o, r, d = sv.step(torch_mod.zeros(128, 4, device="cuda"))
+    assert o.shape == (128, 5) and sv.n_local == 128 and sv.obs_all is None          # world size 1: nothing to gather
