@@ -154,3 +154,22 @@ def test_arm_table_contact_f64(oracle_mod):
     for t in range(420):
         o2.step(a[:1])
     assert oracle_mod.fk_arm(o2.get_state()[0, 0:9], 9)[0][2] < -0.08
+
+
+def test_joint_limit_rows_f64(oracle_mod):
+    """Limit rows active (joints thrown at their limits at 50 rad/s in scripted state 0, where only the weak load-time motors
+    hold the arm): device algorithm == oracle, and the closed form pen / dt of the first step."""
+    N = 2
+    kw = dict(residual_threshold=0.0, warmstart=0.0, enable_self_collision=0, mode=1, dv=0.05)
+    o = oracle_mod.Oracle(N, **kw); e = E.Emul(N, "f64", **kw)
+    s = o.get_state()
+    s[:, 2] = 2.9671 - 0.02; s[:, 11] = 50.0; s[1, 3] = -0.01; s[1, 12] = 30.0; s[:, 18] = 5.0
+    o.set_state(s)
+    for t in range(20):
+        so = o.get_state(); se = e.get_state(); se[:, :98] = so[:, :98]; se[:, 128] = 0; e.set_state(se)
+        o.step(np.zeros((N, 4))); e.step(np.zeros((N, 4)))
+        so = o.get_state(); se = e.get_state()
+        assert np.abs(so[:, POS] - se[:, POS]).max() < 1e-7 and np.abs(so[:, VEL] - se[:, VEL]).max() < 2e-5
+        if t == 0:
+            assert abs(se[0, 11] - 4.8) < 1e-4 and abs(se[1, 12] - 2.4) < 1e-4
+    assert abs(se[0, 2] - 2.9671) < 1e-5 and abs(se[1, 3]) < 1e-5

@@ -247,3 +247,25 @@ def test_arm_table_contact_on_gpu(torch_mod, oracle_mod):
     print("arm-table one-step pose err p50/p99/max = %.2e / %.2e / %.2e" % (np.percentile(perr, 50), np.percentile(perr, 99), perr.max()))
     assert seen > 50 and lowest > -0.05 - 0.004
     assert np.percentile(perr, 50) < 5e-6 and np.percentile(perr, 99) < 1e-4
+
+
+def test_joint_limit_rows_on_gpu(torch_mod, oracle_mod):
+    """Joint-limit rows active (their multipliers live in wave-uniform registers on the GPU): joints thrown at their limits
+    at 50 / 30 rad/s in scripted state 0; closed form pen / dt after the first step, resynchronised parity afterwards."""
+    torch = torch_mod
+    N = 4
+    kw = dict(residual_threshold=0.0, warmstart=0.0, enable_self_collision=0, mode=1, dv=0.05)
+    o = oracle_mod.Oracle(N, **kw); g = _gpu(N, **kw)
+    s = o.get_state()
+    s[:, 2] = 2.9671 - 0.02; s[:, 11] = 50.0; s[1::2, 3] = -0.01; s[1::2, 12] = 30.0; s[:, 18] = 5.0
+    o.set_state(s)
+    perr = []
+    for t in range(20):
+        so = o.get_state(); _to_gpu_state(torch, g, so)
+        o.step(np.zeros((N, 4))); g.step(torch.zeros(N, 4))
+        so = o.get_state(); sg = g.state().cpu().numpy().astype(np.float64)
+        perr.append(np.abs(so[:, POS] - sg[:, POS]).max())
+        if t == 0:
+            assert abs(sg[0, 11] - 4.8) < 2e-3 and abs(sg[1, 12] - 2.4) < 2e-3
+    print("limit-row one-step pose err max = %.2e" % max(perr))
+    assert max(perr) < 2e-5 and abs(sg[0, 2] - 2.9671) < 1e-4 and abs(sg[1, 3]) < 1e-4

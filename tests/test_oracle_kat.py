@@ -192,3 +192,22 @@ def test_coulomb_sliding_decelerates_within_cone(oracle_mod):
         if t_stop is None and abs(vy) < 1e-3:
             t_stop = n
     assert t_stop is not None and t_stop >= 2
+
+
+def test_joint_limit_stops_the_joint(oracle_mod):
+    """Bullet's velocity-level joint limit: a joint 0.02 rad below its upper limit moving at 50 rad/s may keep exactly
+    pen / dt = 0.02 * 240 = 4.8 rad/s in the first step (it arrives AT the limit) and is stopped there afterwards.  Scripted
+    mode, state 0: the arm is held by the weak load-time velocity motors only, so the limit row is what acts."""
+    O = oracle_mod
+    hi3 = 2.9671                                   # Panda joint 3 (index 2) upper limit, include/pih_model.h
+    o = O.Oracle(1, enable_self_collision=0, mode=1, dv=0.05)
+    s = o.get_state()
+    s[0, 2] = hi3 - 0.02; s[0, 9 + 2] = 50.0; s[0, 18] = 5.0     # pipe out of the way
+    o.set_state(s)
+    o.step(np.zeros((1, 4)))
+    st = o.get_state()
+    assert abs(st[0, 11] - 0.02 * 240) < 1e-4 and abs(st[0, 2] - hi3) < 1e-6
+    for t in range(20):
+        o.step(np.zeros((1, 4)))
+        st = o.get_state()
+        assert abs(st[0, 2] - hi3) < 1e-5 and abs(st[0, 11]) < 1e-3
