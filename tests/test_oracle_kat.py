@@ -211,3 +211,33 @@ def test_joint_limit_stops_the_joint(oracle_mod):
         o.step(np.zeros((1, 4)))
         st = o.get_state()
         assert abs(st[0, 2] - hi3) < 1e-5 and abs(st[0, 11]) < 1e-3
+
+
+def test_hole_tube_contact_geometry(oracle_mod):
+    """Signed distance to the annular tube: a straight pipe threaded through the bore, its axis 2 mm short of touching the
+    inner wall from above... i.e. the sphere surfaces 2 mm from the bore's bottom: every sample inside the tube's length gets
+    a contact with the exact radial normal (+z), depth 0.002 and the contact point on the common normal."""
+    O = oracle_mod
+    hole = np.array([0.5, -0.2, 0.2]); rin, r, hl = 0.01536, 0.01, 0.016
+    o = O.Oracle(1, enable_self_collision=0)
+    s = o.get_state()
+    s[0, 31:54] = 0                                              # straight pipe
+    q = np.array([0, 0, np.sin(-np.pi / 4), np.cos(-np.pi / 4)])  # local y -> world x
+    rho = rin - r - 0.002                                         # distance of the pipe axis below the bore axis
+    s[0, 18:21] = [hole[0] - 0.30, hole[1], hole[2] - rho]; s[0, 21:25] = q
+    s[0, 25:31] = 0
+    o.set_state(s)
+    o.step(np.array([[0.3, 0.0, 0.5, 0.0]]))
+    c = o.debug_contacts(0)
+    tube = c[(c[:, 10] >= 100) & (c[:, 10] < 300)]
+    assert len(tube) >= 3
+    inside = tube[np.abs(tube[:, 2] - hole[0]) <= hl]
+    assert len(inside) >= 2
+    np.testing.assert_allclose(inside[:, 5:8], np.tile([0, 0, 1.0], (len(inside), 1)), atol=1e-9)
+    np.testing.assert_allclose(inside[:, 8], 0.002, atol=1e-9)
+    # contact point: on the sphere-centre -> wall normal, half the gap beyond the sphere surface (z = centre - r - depth/2)
+    np.testing.assert_allclose(inside[:, 4], hole[2] - rho - r - 0.001, atol=1e-9)
+    np.testing.assert_allclose(inside[:, 3], hole[1], atol=1e-12)
+    # samples beyond the tube's ends see its rim: their normals tilt outwards along the axis and the gap grows
+    outside = tube[np.abs(tube[:, 2] - hole[0]) > hl + 1e-6]
+    assert (outside[:, 8] > 0.002).all() and (np.abs(outside[:, 5]) > 0).all()
