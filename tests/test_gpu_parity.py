@@ -269,3 +269,30 @@ def test_joint_limit_rows_on_gpu(torch_mod, oracle_mod):
             assert abs(sg[0, 11] - 4.8) < 2e-3 and abs(sg[1, 12] - 2.4) < 2e-3
     print("limit-row one-step pose err max = %.2e" % max(perr))
     assert max(perr) < 2e-5 and abs(sg[0, 2] - 2.9671) < 1e-4 and abs(sg[1, 3]) < 1e-4
+
+
+def test_tube_contacts_on_gpu(torch_mod, oracle_mod):
+    """Hole-tube contacts (signed distance to the annular tube) are rare in random rollouts: a straight pipe threaded through
+    the bore and dropped onto its inner wall, GPU resynchronised to the oracle before every step."""
+    torch = torch_mod
+    N = 4
+    hole = np.array([0.5, -0.2, 0.2]); rin, r = 0.01536, 0.01
+    kw = dict(residual_threshold=0.0, warmstart=0.0, enable_self_collision=0)
+    o = oracle_mod.Oracle(N, **kw); g = _gpu(N, **kw)
+    s = o.get_state()
+    s[:, 31:54] = 0
+    s[:, 18] = hole[0] - np.array([0.30, 0.45, 0.60, 0.75]); s[:, 19] = hole[1]; s[:, 20] = hole[2] - (rin - r - 0.002)
+    s[:, 21:25] = [0, 0, np.sin(-np.pi / 4), np.cos(-np.pi / 4)]; s[:, 25:31] = 0
+    o.set_state(s)
+    a = np.tile([0.3, 0.0, 0.5, 0.0], (N, 1))
+    ntube = 0; perr = []
+    for t in range(60):
+        so = o.get_state(); _to_gpu_state(torch, g, so)
+        o.step(a); g.step(torch.tensor(a, dtype=torch.float32))
+        so = o.get_state(); sg = g.state().cpu().numpy().astype(np.float64)
+        np.testing.assert_array_equal(o.ncontacts(), sg[:, 106].astype(int))
+        ntube += sum(100 <= int(k) < 300 for k in o.debug_contacts(0)[:, 10])
+        perr.append(np.abs(so[:, POS] - sg[:, POS]).max(1))
+    perr = np.concatenate(perr)
+    print("tube-contact one-step pose err p50/p99/max = %.2e / %.2e / %.2e" % (np.percentile(perr, 50), np.percentile(perr, 99), perr.max()))
+    assert ntube > 100 and np.percentile(perr, 50) < 5e-6 and np.percentile(perr, 99) < 2e-4
