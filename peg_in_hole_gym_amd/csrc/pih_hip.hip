@@ -173,12 +173,24 @@ __global__ void __launch_bounds__(256) pih_labels_kernel(const float* __restrict
   const int e = blockIdx.y, env = env_begin + e;
   const float angle = state[(size_t)env * PIH_STATE_WORDS + PIH_S_GRASP_ANGLE];
   const LabelRect L = label_rect(angle, S);
-  const int idx = blockIdx.x * 256 + threadIdx.x, SS = S * S;
-  if (idx < SS) {
-    const int c = idx / S, r = idx - c * S;              // element [c][r] of the image
-    const bool in = label_inside(L, (float)c, (float)r);
-    float* o = out + (size_t)e * 4 * SS;
-    o[idx] = in ? 50.0f : 0.0f; o[SS + idx] = in ? L.s2 : 0.0f; o[2 * SS + idx] = in ? L.c2 : 1.0f; o[3 * SS + idx] = in ? L.wpx : 0.0f;
+  // each thread owns 4 consecutive pixels and writes one 16-byte store per label plane (the kernel is pure HBM writes)
+  const int SS = S * S, i4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  float* o = out + (size_t)e * 4 * SS;
+  if (i4 < SS) {
+    float v[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int idx = i4 + k < SS ? i4 + k : SS - 1;
+      const int c = idx / S, r = idx - c * S;            // element [c][r] of the image
+      const bool in = label_inside(L, (float)c, (float)r);
+      v[0][k] = in ? 50.0f : 0.0f; v[1][k] = in ? L.s2 : 0.0f; v[2][k] = in ? L.c2 : 1.0f; v[3][k] = in ? L.wpx : 0.0f;
+    }
+    const bool vec = (i4 + 3 < SS) && ((SS & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++) {
+      if (vec) *reinterpret_cast<float4*>(o + (size_t)pl * SS + i4) = make_float4(v[pl][0], v[pl][1], v[pl][2], v[pl][3]);
+      else for (int k = 0; k < 4 && i4 + k < SS; k++) o[(size_t)pl * SS + i4 + k] = v[pl][k];
+    }
   }
   if (meta && blockIdx.x == 0 && threadIdx.x == 0) {
     float* m = meta + (size_t)e * 5;
@@ -379,7 +391,7 @@ int pih_grasp_labels(pih_handle* h, float* out_dev, float* meta_dev, int size, i
     if (h) h->err = "pih_grasp_labels: bad arguments";
     return -2;
   }
-  hipLaunchKernelGGL(pih_labels_kernel, dim3((size * size + 255) / 256, env_count), dim3(256), 0, (hipStream_t)stream, h->state, out_dev, meta_dev, env_begin, size);
+  hipLaunchKernelGGL(pih_labels_kernel, dim3((size * size + 1023) / 1024, env_count), dim3(256), 0, (hipStream_t)stream, h->state, out_dev, meta_dev, env_begin, size);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -121,3 +121,9 @@ def test_hip_render_matches_oracle():
         for k in (1, 2, 3):
             assert np.abs(lab[e, k] - lo[k])[agree].max() < 1e-4
         assert np.allclose(meta[e], mo, atol=2e-3)
+    # a size whose pixel count is not a multiple of 4 takes the scalar-store tail of the label kernel
+    lab61, _ = g.grasp_labels(61)
+    lab61 = lab61.cpu().numpy()
+    for e in range(n):
+        lo, _ = O.grasp_labels(ang[e], 61)
+        assert lab61.shape == (n, 4, 61, 61) and (lab61[e, 0] != lo[0]).sum() <= 12 and np.abs(lab61[e, 2] - lo[2])[lab61[e, 0] == lo[0]].max() < 1e-4
