@@ -31,7 +31,7 @@ constexpr int NL = PIH_NL, ANL = PIH_ARM_NL, ONL = PIH_OBJ_NL, ND = PIH_NDOF;
 constexpr int NSAMP = PIH_PIPE_NSAMP;
 constexpr int CMAX = 48;      // contacts per env
 constexpr int CAMAX = 12;     // of which may involve the arm (same cap as the oracle's PIHO_CAMAX)
-constexpr int CL = 16;        // contacts whose solver data live in LDS; contacts CL..CMAX-1 spill to a global scratch
+constexpr int CL = 20;        // contacts whose solver data live in LDS; contacts CL..CMAX-1 spill to a global scratch
 constexpr int NROWC = 3 * CMAX;
 constexpr int CREC = 32;      // words per packed contact record
 constexpr int WPS = 39;       // LDS row stride of a contact response row: entry d = DOF d (9 arm + 29 pipe), word 38 = 0 (read by idle lanes)
@@ -127,7 +127,7 @@ struct ArenaB {
 };
 constexpr int WMA_OFF = PIH_OBJ_NJ * WMS;   // word offset of Wma inside the staging block
 constexpr int WSTAGE = 3 * CL * WPS - (WMA_OFF + 81);   // the staging block sits at the END of ArenaB::Wp ...
-constexpr int MERGED_CONTACTS = 9;          // ... so the response rows of the first 9 contacts can be written in the same pass
+constexpr int MERGED_CONTACTS = 10;          // ... so the response rows of the first 9 contacts can be written in the same pass
 static_assert(WSTAGE >= 3 * MERGED_CONTACTS * WPS, "motor staging must not overlap the rows of the merged contacts");
 
 struct Shared {
@@ -1501,18 +1501,31 @@ template <class W> PIH_HD int pgs(W& w, Shared& sh, const Params& P, const Ovf& 
       for (;;) {
         const int c1 = c + 1 < ncl ? c + 1 : c;
         CRec rb = fetch(sh.b.crec[c1], &sh.b.Wp[3 * c1][0]);
-        block(c, sg0, ra, sh.b.crec[c], true);
+        block(c, c < 16 ? sg0 : sg1, ra, sh.b.crec[c], true);
         if (++c >= ncl) break;
         const int c2 = c + 1 < ncl ? c + 1 : c;
         ra = fetch(sh.b.crec[c2], &sh.b.Wp[3 * c2][0]);
-        block(c, sg0, rb, sh.b.crec[c], true);
+        block(c, c < 16 ? sg0 : sg1, rb, sh.b.crec[c], true);
         if (++c >= ncl) break;
       }
     }
-    for (int c = CL; c < nc; c++) {
-      real* R = ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC;
-      CRec r = fetch(R, ov.base + (size_t)(3 * (c - CL)) * WPS);
-      block(c, c < 32 ? sg1 : sg2, r, R, false);
+    if (nc > CL) {
+      // the spilled contacts (global scratch) with the same one-ahead ping-pong: an env that gets here is one of the heaviest of
+      // the launch, i.e. the one the launch ends up waiting for, and an unprefetched global load per contact is its latency
+      auto rec_of = [&](int c) { return ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC; };
+      auto row_of = [&](int c) { return ov.base + (size_t)(3 * (c - CL)) * WPS; };
+      CRec ra = fetch(rec_of(CL), row_of(CL));
+      int c = CL;
+      for (;;) {
+        const int c1 = c + 1 < nc ? c + 1 : c;
+        CRec rb = fetch(rec_of(c1), row_of(c1));
+        block(c, c < 32 ? sg1 : sg2, ra, rec_of(c), false);
+        if (++c >= nc) break;
+        const int c2 = c + 1 < nc ? c + 1 : c;
+        ra = fetch(rec_of(c2), row_of(c2));
+        block(c, c < 32 ? sg1 : sg2, rb, rec_of(c), false);
+        if (++c >= nc) break;
+      }
     }
     return !((busy >> 32) & 1ull);
   };
