@@ -127,7 +127,7 @@ struct ArenaB {
 };
 constexpr int WMA_OFF = PIH_OBJ_NJ * WMS;   // word offset of Wma inside the staging block
 constexpr int WSTAGE = 3 * CL * WPS - (WMA_OFF + 81);   // the staging block sits at the END of ArenaB::Wp ...
-constexpr int MERGED_CONTACTS = 10;          // ... so the response rows of the first 9 contacts can be written in the same pass
+constexpr int MERGED_CONTACTS = 10;          // ... so the response rows of the first 10 contacts can be written in the same pass
 static_assert(WSTAGE >= 3 * MERGED_CONTACTS * WPS, "motor staging must not overlap the rows of the merged contacts");
 
 struct Shared {
@@ -1143,8 +1143,8 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
   link_velocities(w, sh);
   // Response rows (lane = row): global row g < 32 is a motor row (unit joint impulse; the limit rows share its W and
   // 1/(J W)), row 32 + 3c + k is row k of contact c (k = 0 normal, 1/2 friction directions).  ONE call site of response()
-  // serves both kinds with per-lane arguments, and the first pass takes the 32 motor rows together with the first 9 contacts
-  // (27 rows: their response rows end below the words the motor rows are staged in), so an env with <= 9 contacts pays for
+  // serves both kinds with per-lane arguments, and the first pass takes the 32 motor rows together with the first 10 contacts
+  // (30 rows: their response rows end below the words the motor rows are staged in), so an env with <= 10 contacts pays for
   // one sweep of the articulated system instead of two.
   const int nrows = NMOT + 3 * sh.nc;
   constexpr int FIRST = NMOT + 3 * MERGED_CONTACTS;
