@@ -41,3 +41,15 @@ def test_create_fails_loudly_without_gpu():
     from peg_in_hole_gym_amd.vec_env import PihVecEnv
     with pytest.raises(_lib.PihError):
         PihVecEnv(4)
+
+
+def test_missing_extension_fails_loudly():
+    """No CPU fallback: with the HIP library absent the product raises PihError naming the build command (fresh interpreter,
+    PIH_LIB_PATH pointing nowhere)."""
+    import subprocess, sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['PIH_LIB_PATH'] = '/nonexistent/libpih_hip.so'\n"
+            "from peg_in_hole_gym_amd import _lib\n"
+            "try:\n    _lib.load(); print('LOADED')\n"
+            "except _lib.PihError as e:\n    print('PihError:', e)\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "PihError:" in out.stdout and "no CPU fallback" in out.stdout and "LOADED" not in out.stdout, out.stdout + out.stderr
