@@ -9,7 +9,7 @@ env = PihVecEnv(n, auto_reset=0 if lift else 1, debug=2, enable_self_collision=0
 if lift:
     st = env.state(); st[:, 20] = 50.0; env.set_state(st)   # no contacts at all: motor/limit rows only
 gen = torch.Generator(device="cuda").manual_seed(1234)
-names = ["fk", "controller+IK", "collide", "aba", "build_rows", "pgs", "integrate", "fk2"]
+names = ["fk", "fsm+motor targets", "collide", "aba", "build_rows", "pgs", "integrate", "fk2"]   # the controller / IK itself runs in pih_pre_kernel
 acc = torch.zeros(8, device="cuda")
 for t in range(300):
     env.step(torch.rand(n, 4, device="cuda", generator=gen) * 2 - 1)
