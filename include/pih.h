@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIH_ABI_VERSION 2
+#define PIH_ABI_VERSION 3
 #define PIH_STATE_WORDS 256   /* float words per env record: [0,128) physical state, [128,256) warm-start contact cache */
 #define PIH_ACTION_DIM 4      /* envs/peg_in_hole.py:12 */
 #define PIH_OBS_DIM 5         /* envs/peg_in_hole.py:13: finger1, finger2, ee x, y, z */
@@ -38,7 +38,8 @@ extern "C" {
 enum {
   PIH_S_QARM = 0, PIH_S_QDARM = 9, PIH_S_POS = 18, PIH_S_QUAT = 21, PIH_S_VLIN = 25, PIH_S_VANG = 28,
   PIH_S_QJ = 31, PIH_S_QDJ = 54, PIH_S_TARGET = 77,
-  PIH_S_FSM = 86, PIH_S_FSMT = 87, PIH_S_DONE = 88, PIH_S_GRASP = 89, PIH_S_RANDY = 90, PIH_S_ATTACH = 91,
+  PIH_S_FSM = 86, PIH_S_FSMT = 87, PIH_S_DONE = 88, PIH_S_GRASP = 89, PIH_S_RANDY = 90,
+  PIH_S_RNG_HI = 91,       /* draw counter of the env's RNG = RNG_HI * 2^24 + RNG (two exact fp32 integers: 2^48 draws) */
   PIH_S_RNG = 92, PIH_S_STEPS = 93, PIH_S_OFFSET = 94,
   PIH_S_SPARE = 97,        /* number of times this env was reset because its state became non-finite */
   PIH_S_TIP = 98,          /* peg-tip pose xyz + quat(xyzw) after the last step (7) */
@@ -47,6 +48,7 @@ enum {
   PIH_S_PGS_ITERS = 107,   /* PGS iterations actually executed in the last step */
   PIH_S_EE = 108,          /* world position of the grasp-target frame (pybullet link 11) after the last step / reset (3) */
   PIH_S_GRASP_ANGLE = 111, /* scripted mode: atan2 of the rotated grasp offset when the state machine entered state 2 (envs/peg_in_hole.py:72) */
+  PIH_S_INVALID = 112,     /* 1: the state became non-finite while auto_reset = 0; the env was re-initialised, marked done and stays frozen until pih_reset */
   PIH_S_CACHE_N = 128, PIH_S_CACHE_KEY = 129, PIH_S_CACHE_LAMBDA = 129 + 48
 };
 
@@ -57,6 +59,12 @@ enum {
   PIH_FIELD_CONTACT_FORCE = 2, /* float[n]     (get only)  north_star contact-normal force */
   PIH_FIELD_DEBUG = 3,         /* float[n, PIH_DEBUG_WORDS] (get only; filled when config.debug != 0) */
   PIH_FIELD_EE_POS = 4         /* float[n, 3]  (get only)  envs/utils.py:62 getLinkState(panda, 11)[0] */
+};
+
+/* tasks (the reference's TASK_LIST registry, envs/base_env.py:9-11; README.md:38 names 'random-fly') */
+enum {
+  PIH_TASK_PEG_IN_HOLE = 0,   /* Panda + 25-link pipe + hole tube + table (envs/peg_in_hole.py) */
+  PIH_TASK_RANDOM_FLY = 1     /* UR5 + one free-flying object (README.md:38; ur_execute, envs/utils.py:70-82); see pih_fly.h */
 };
 
 typedef struct pih_config {
@@ -71,6 +79,7 @@ typedef struct pih_config {
   int32_t debug;              /* 1: fill the debug buffer each step */
   int32_t schedule;           /* 1 (default): longest-job-first dispatch order from the previous step's contact counts; 0: block i = env i */
   int32_t enable_arm_collision; /* 1 (default): arm collision spheres (pih_model.h PIH_ARM_SPH_*) vs the table plane */
+  int32_t task_id;            /* PIH_TASK_*: which task of TASK_LIST (envs/base_env.py:9-11) the handle simulates */
   uint64_t seed;
   float dt;                   /* 1/240 */
   float residual_threshold;   /* 1e-7 */
@@ -91,8 +100,12 @@ int pih_abi_version(void);
 /* offsets_host: HOST float[n_envs,3] (envs/base_env.py:35-55 placement) or NULL for zeros */
 int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** out);
 int pih_destroy(pih_handle* h);
-/* mask_dev: uint8[n] (nonzero = reset that env) or NULL = all.  hard is accepted for API parity (envs/base_env.py:85) */
+/* mask_dev: uint8[n] (nonzero = reset that env) or NULL = all.  hard != 0 (resetSimulation, envs/base_env.py:85-86): the env
+ * also forgets its RNG draw counter and its non-finite-reset count, i.e. it replays the scene sequence of its seed from the start */
 int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, void* stream);
+/* new base seed for all later resets (env seed = seed + 1000 + global env index); combine with a hard reset to restart the
+ * draw sequence.  The reference never seeds (envs/peg_in_hole.py:239-267 use the global `random`). */
+int pih_reseed(pih_handle* h, uint64_t seed);
 /* actions_dev float[n,4]; obs_dev float[n,5]; reward_dev float[n]; done_dev uint8[n] */
 int pih_step(pih_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 /* k consecutive steps with the same action buffer (scripted mode ignores actions: may be NULL) in one call */
@@ -113,8 +126,10 @@ int pih_render(pih_handle* h, float* out_dev, int width, int height, int env_beg
  * sin(2 angle), cos(2 angle), width in pixels; meta_dev (may be NULL) float[env_count, 5] = x, y, angle [deg], width, length.
  * The reference rasterises with skimage.draw.polygon (absent here: parity unpinned); restated as its even-odd crossing test. */
 int pih_grasp_labels(pih_handle* h, float* out_dev, float* meta_dev, int size, int env_begin, int env_count, void* stream);
-/* kernel timing with HIP events on `stream`: average ms per pih_step launch since the last call with reset=1 */
+/* kernel timing with HIP events on the launch stream: average ms per step (pre-kernel + step kernel) since the last call with
+ * reset=1; pih_timing2 also splits it into the controller/sort launch and the physics launch */
 int pih_timing(pih_handle* h, int reset, double* avg_ms_out, int64_t* launches_out);
+int pih_timing2(pih_handle* h, int reset, double* pre_ms_out, double* step_ms_out, int64_t* launches_out);
 int pih_set_timing(pih_handle* h, int enable);
 const char* pih_last_error(pih_handle* h);
 

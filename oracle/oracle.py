@@ -43,6 +43,8 @@ def lib(omp=False):
         L.piho_create.argtypes = [C.POINTER(Config), dp]
         L.piho_destroy.argtypes = [C.c_void_p]
         L.piho_reset.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.piho_reset_hard.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.piho_reseed.argtypes = [C.c_void_p, C.c_uint64]
         L.piho_step.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_uint8)]
         for f in ("piho_get_state", "piho_get_tip_pose", "piho_get_contact_force"):
             getattr(L, f).argtypes = [C.c_void_p, dp]
@@ -87,11 +89,14 @@ class Oracle:
             self.L.piho_destroy(self.h)
             self.h = None
 
-    def reset(self, mask=None):
+    def reset(self, mask=None, hard_reset=False):
         m = None
         if mask is not None:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
-        self.L.piho_reset(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None)
+        (self.L.piho_reset_hard if hard_reset else self.L.piho_reset)(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None)
+
+    def reseed(self, seed):
+        self.L.piho_reseed(self.h, int(seed))
 
     def step(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n, 4)

@@ -508,7 +508,7 @@ static void reset_env(piho_handle* h, int e) {
   Env* E = &h->env[e];
   double* s = E->s;
   double off[3] = {s[PIHO_S_OFFSET], s[PIHO_S_OFFSET + 1], s[PIHO_S_OFFSET + 2]}, nbad = s[PIHO_S_SPARE];
-  uint64_t ctr = (uint64_t)s[PIHO_S_RNG];
+  uint64_t ctr = ((uint64_t)s[PIHO_S_RNG_HI] << 24) + (uint64_t)s[PIHO_S_RNG];   /* same two-word counter as the product's fp32 record */
   uint64_t seed = h->cfg.seed + 1000ULL + (uint64_t)(h->cfg.env_index0 + e);
   memset(s, 0, sizeof(double) * PIHO_STATE_WORDS);
   for (int k = 0; k < 3; k++) s[PIHO_S_OFFSET + k] = off[k];
@@ -531,7 +531,7 @@ static void reset_env(piho_handle* h, int e) {
   }
   s[PIHO_S_GRASP] = (rng24(seed, ctr++) >> 23) ? 23 : 0;             /* choice([0, 23]) :266 */
   s[PIHO_S_RANDY] = -0.03 + 0.06 * (rng24(seed, ctr++) * U);         /* uniform(-0.03, 0.03) :267 */
-  s[PIHO_S_RNG] = (double)ctr;
+  s[PIHO_S_RNG] = (double)(ctr & 0xFFFFFFull); s[PIHO_S_RNG_HI] = (double)((ctr >> 24) & 0xFFFFFFull);
   E->ncache = 0; E->ncontacts = 0; E->contact_force = 0;
   LinkKin K[NL];
   fk(&s[PIHO_S_QARM], &s[PIHO_S_POS], &s[PIHO_S_QUAT], &s[PIHO_S_QJ], ANL, NL, K);
@@ -540,6 +540,13 @@ static void reset_env(piho_handle* h, int e) {
 void piho_reset(piho_handle* h, const uint8_t* mask) {
   for (int e = 0; e < h->cfg.n_envs; e++) if (!mask || mask[e]) reset_env(h, e);
 }
+void piho_reset_hard(piho_handle* h, const uint8_t* mask) {
+  for (int e = 0; e < h->cfg.n_envs; e++) if (!mask || mask[e]) {
+    h->env[e].s[PIHO_S_RNG] = 0; h->env[e].s[PIHO_S_RNG_HI] = 0; h->env[e].s[PIHO_S_SPARE] = 0;
+    reset_env(h, e);
+  }
+}
+void piho_reseed(piho_handle* h, uint64_t seed) { h->cfg.seed = seed; }
 
 /* ------------------------------------------------------------------------------------------ collision */
 static int add_contact(Env* E, int linkA, int linkB, int key, const v3 p, const v3 n, double depth, double mu) {
@@ -896,8 +903,12 @@ static void step_env(piho_handle* h, int e, const double* action, double* obs, d
   obs[0] = s[PIHO_S_QARM + 7]; obs[1] = s[PIHO_S_QARM + 8];
   for (int k = 0; k < 3; k++) obs[2 + k] = eep[k] + s[PIHO_S_OFFSET + k];
   *reward = rew; *done = (uint8_t)(s[PIHO_S_DONE] != 0 || bad);
-  if (bad) { if (!isfinite(s[PIHO_S_RNG])) s[PIHO_S_RNG] = 0; s[PIHO_S_SPARE] = (isfinite(s[PIHO_S_SPARE]) ? s[PIHO_S_SPARE] : 0) + 1; }
-  if (bad || (c->auto_reset && s[PIHO_S_DONE] != 0)) reset_env(h, e);
+  if (bad) { if (!isfinite(s[PIHO_S_RNG])) s[PIHO_S_RNG] = 0; if (!isfinite(s[PIHO_S_RNG_HI])) s[PIHO_S_RNG_HI] = 0;
+             s[PIHO_S_SPARE] = (isfinite(s[PIHO_S_SPARE]) ? s[PIHO_S_SPARE] : 0) + 1; }
+  if (bad || (c->auto_reset && s[PIHO_S_DONE] != 0)) {
+    reset_env(h, e);
+    if (bad && !c->auto_reset) { s[PIHO_S_DONE] = 1; s[PIHO_S_INVALID] = 1; }   /* frozen + flagged until the caller resets it */
+  }
 }
 
 void piho_step(piho_handle* h, const double* actions, double* obs, double* reward, uint8_t* done) {

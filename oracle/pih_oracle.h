@@ -28,8 +28,8 @@ extern "C" {
 enum {
   PIHO_S_QARM = 0, PIHO_S_QDARM = 9, PIHO_S_POS = 18, PIHO_S_QUAT = 21, PIHO_S_VLIN = 25, PIHO_S_VANG = 28,
   PIHO_S_QJ = 31, PIHO_S_QDJ = 54, PIHO_S_TARGET = 77,
-  PIHO_S_FSM = 86, PIHO_S_FSMT = 87, PIHO_S_DONE = 88, PIHO_S_GRASP = 89, PIHO_S_RANDY = 90, PIHO_S_ATTACH = 91,
-  PIHO_S_RNG = 92, PIHO_S_STEPS = 93, PIHO_S_OFFSET = 94, PIHO_S_SPARE = 97, PIHO_S_GRASP_ANGLE = 111
+  PIHO_S_FSM = 86, PIHO_S_FSMT = 87, PIHO_S_DONE = 88, PIHO_S_GRASP = 89, PIHO_S_RANDY = 90, PIHO_S_RNG_HI = 91,
+  PIHO_S_RNG = 92, PIHO_S_STEPS = 93, PIHO_S_OFFSET = 94, PIHO_S_SPARE = 97, PIHO_S_GRASP_ANGLE = 111, PIHO_S_INVALID = 112
 };
 
 typedef struct {
@@ -60,6 +60,8 @@ void piho_default_config(piho_config* c);
 piho_handle* piho_create(const piho_config* c, const double* offsets /* [n,3] or NULL */);
 void piho_destroy(piho_handle* h);
 void piho_reset(piho_handle* h, const uint8_t* mask /* [n] or NULL = all */);
+void piho_reset_hard(piho_handle* h, const uint8_t* mask);   /* also forgets the RNG draw counter and the non-finite-reset count */
+void piho_reseed(piho_handle* h, uint64_t seed);
 /* actions [n,4]; obs [n,5]; reward [n]; done [n] */
 void piho_step(piho_handle* h, const double* actions, double* obs, double* reward, uint8_t* done);
 void piho_get_state(const piho_handle* h, double* out /* [n,128] */);

@@ -13,18 +13,20 @@ OBS_DIM = 5
 FIELD_STATE, FIELD_TIP_POSE, FIELD_CONTACT_FORCE, FIELD_DEBUG, FIELD_EE_POS = 0, 1, 2, 3, 4
 # state record word offsets (include/pih.h)
 S_QARM, S_QDARM, S_POS, S_QUAT, S_VLIN, S_VANG, S_QJ, S_QDJ, S_TARGET = 0, 9, 18, 21, 25, 28, 31, 54, 77
-S_FSM, S_FSMT, S_DONE, S_GRASP, S_RANDY, S_ATTACH, S_RNG, S_STEPS, S_OFFSET = 86, 87, 88, 89, 90, 91, 92, 93, 94
-S_TIP, S_CFORCE, S_NCONTACT, S_PGS_ITERS, S_CACHE_N = 98, 105, 106, 107, 128
+S_FSM, S_FSMT, S_DONE, S_GRASP, S_RANDY, S_RNG_HI, S_RNG, S_STEPS, S_OFFSET = 86, 87, 88, 89, 90, 91, 92, 93, 94
+S_SPARE, S_TIP, S_CFORCE, S_NCONTACT, S_PGS_ITERS, S_INVALID, S_CACHE_N = 97, 98, 105, 106, 107, 112, 128
+TASK_PEG_IN_HOLE, TASK_RANDOM_FLY = 0, 1
+ABI_VERSION = 3
 
-EXPORTS = ["pih_default_config", "pih_abi_version", "pih_create", "pih_destroy", "pih_reset", "pih_step", "pih_step_n",
-           "pih_get_state", "pih_set_state", "pih_ik", "pih_ik_ur5", "pih_render", "pih_grasp_labels", "pih_timing", "pih_set_timing", "pih_last_error"]
+EXPORTS = ["pih_default_config", "pih_abi_version", "pih_create", "pih_destroy", "pih_reset", "pih_reseed", "pih_step", "pih_step_n",
+           "pih_get_state", "pih_set_state", "pih_ik", "pih_ik_ur5", "pih_render", "pih_grasp_labels", "pih_timing", "pih_timing2", "pih_set_timing", "pih_last_error"]
 
 
 class PihConfig(C.Structure):
     """struct pih_config (include/pih.h)"""
     _fields_ = [("n_envs", C.c_int32), ("env_index0", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32),
                 ("ik_iters", C.c_int32), ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32),
-                ("enable_self_collision", C.c_int32), ("debug", C.c_int32), ("schedule", C.c_int32), ("enable_arm_collision", C.c_int32), ("seed", C.c_uint64),
+                ("enable_self_collision", C.c_int32), ("debug", C.c_int32), ("schedule", C.c_int32), ("enable_arm_collision", C.c_int32), ("task_id", C.c_int32), ("seed", C.c_uint64),
                 ("dt", C.c_float), ("residual_threshold", C.c_float), ("erp", C.c_float), ("warmstart", C.c_float),
                 ("contact_margin", C.c_float), ("linear_slop", C.c_float), ("ik_damping", C.c_float), ("ik_residual", C.c_float),
                 ("dv", C.c_float), ("reserved_f", C.c_float * 3)]
@@ -64,10 +66,14 @@ def load():
     L.pih_ik_ur5.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.pih_render.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.pih_grasp_labels.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.pih_reseed.argtypes = [vp, C.c_uint64]
     L.pih_timing.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.pih_timing2.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.pih_set_timing.argtypes = [vp, C.c_int]
     L.pih_last_error.argtypes = [vp]
     L.pih_last_error.restype = C.c_char_p
+    if L.pih_abi_version() != ABI_VERSION:
+        raise PihError("%s has ABI version %d, this package expects %d: rebuild it" % (LIB_PATH, L.pih_abi_version(), ABI_VERSION))
     _lib = L
     return L
 

@@ -437,7 +437,8 @@ template <class C, class W> PIH_HD void ik_chain(W& w, real (*ik_T)[12], const P
 // envs/peg_in_hole.py:227-274 with the RNG draw order of SURVEY.md App. E (own counter RNG).  Wave-uniform.
 PIH_HD void reset_state(real* S, const Params& P, int env_global) {
   real off0 = S[PIH_S_OFFSET], off1 = S[PIH_S_OFFSET + 1], off2 = S[PIH_S_OFFSET + 2], nbad = S[PIH_S_SPARE];
-  uint64_t ctr = (uint64_t)S[PIH_S_RNG];
+  // draw counter = RNG_HI * 2^24 + RNG: two exact fp32 integers (one fp32 word alone is exact only up to 2^24 draws)
+  uint64_t ctr = ((uint64_t)S[PIH_S_RNG_HI] << 24) + (uint64_t)S[PIH_S_RNG];
   uint64_t seed = P.seed + 1000ULL + (uint64_t)env_global;
   for (int i = 0; i < PIH_STATE_WORDS; i++) S[i] = 0;
   S[PIH_S_OFFSET] = off0; S[PIH_S_OFFSET + 1] = off1; S[PIH_S_OFFSET + 2] = off2; S[PIH_S_SPARE] = nbad;
@@ -467,7 +468,7 @@ PIH_HD void reset_state(real* S, const Params& P, int env_global) {
   }
   S[PIH_S_GRASP] = (rng24(seed, ctr++) >> 23) ? (real)23 : (real)0;
   S[PIH_S_RANDY] = (real)-0.03 + (real)0.06 * ((real)rng24(seed, ctr++) * U);
-  S[PIH_S_RNG] = (real)ctr;
+  S[PIH_S_RNG] = (real)(ctr & 0xFFFFFFull); S[PIH_S_RNG_HI] = (real)((ctr >> 24) & 0xFFFFFFull);
 }
 
 // ------------------------------------------------------------------------------------------------ controller
@@ -1650,9 +1651,13 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, const Ovf& ov, int env, 
   *reward = rew; *done = (unsigned char)((S[PIH_S_DONE] != 0 || bad) ? 1 : 0);
   w.sync();
   if (bad || (P.autoreset && S[PIH_S_DONE] != 0)) {
-    if (bad) { S[PIH_S_RNG] = (finite_small(S[PIH_S_RNG]) && S[PIH_S_RNG] >= 0 && S[PIH_S_RNG] < (real)1e7) ? S[PIH_S_RNG] : (real)0;
+    if (bad) { S[PIH_S_RNG] = (finite_small(S[PIH_S_RNG]) && S[PIH_S_RNG] >= 0 && S[PIH_S_RNG] < (real)16777216) ? S[PIH_S_RNG] : (real)0;
+               S[PIH_S_RNG_HI] = (finite_small(S[PIH_S_RNG_HI]) && S[PIH_S_RNG_HI] >= 0 && S[PIH_S_RNG_HI] < (real)16777216) ? S[PIH_S_RNG_HI] : (real)0;
                real nb = S[PIH_S_SPARE]; S[PIH_S_SPARE] = (finite_small(nb) && nb >= 0 ? nb : (real)0) + 1; }   // count non-finite resets
     reset_state(S, P, P.env0 + env);
+    // auto_reset = 0 (the reference-shaped facade): a non-finite env does not silently start a second episode -- it is put back
+    // into a finite initial state, reported done, flagged invalid, and stays frozen until the caller resets it
+    if (bad && !P.autoreset) { S[PIH_S_DONE] = 1; S[PIH_S_INVALID] = 1; }
     w.sync();
     fk_all(w, sh);
     real tp2[7]; tip_pose(sh, tp2);

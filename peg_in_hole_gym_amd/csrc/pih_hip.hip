@@ -78,13 +78,15 @@ __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __rest
   if (lane == 0) { if (reward) reward[env] = r; if (done) done[env] = d; }
 }
 
-__global__ void __launch_bounds__(64) pih_reset_kernel(Params P, float* __restrict__ state, const unsigned char* __restrict__ mask) {
+__global__ void __launch_bounds__(64) pih_reset_kernel(Params P, float* __restrict__ state, const unsigned char* __restrict__ mask, int hard) {
   __shared__ Shared sh;
   const int env = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[env]) return;
   Wave w; w.l = lane; w.counter = 0;
   float* rec = state + (size_t)env * PIH_STATE_WORDS;
   for (int i = 0; i < PIH_STATE_WORDS / 64; i++) sh.S[lane + 64 * i] = rec[lane + 64 * i];
+  __syncthreads();
+  if (hard) { sh.S[PIH_S_RNG] = 0; sh.S[PIH_S_RNG_HI] = 0; sh.S[PIH_S_SPARE] = 0; }   // resetSimulation: replay the seed's scene sequence from the start
   __syncthreads();
   reset_state(sh.S, P, P.env0 + env);
   __syncthreads();
@@ -206,18 +208,21 @@ __global__ void pih_gather_kernel(const float* __restrict__ state, float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+constexpr size_t EV_POOL = 1024;   // timing event triples kept before they are folded into the running sums
+struct EvTriple { hipEvent_t a, b, c; };
 struct pih_handle {
   pih_config cfg;
   Params P;
-  int device;
+  int device = 0;
   float* state = nullptr;
   float* dbg = nullptr;
   float* ovf = nullptr;     // spill area for contacts beyond the LDS-resident CL (rarely touched)
   int* order = nullptr;     // longest-job-first block -> env map (block 0 of pih_pre_kernel)
   std::string err;
   bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // event pairs bracketing each step launch
+  std::vector<EvTriple> ev;   // (before pre-kernel, between, after step kernel) of each timed step launch
   size_t ev_used = 0;
+  double acc_pre_ms = 0, acc_step_ms = 0; int64_t acc_n = 0;
 };
 
 static thread_local std::string g_err;
@@ -230,6 +235,18 @@ static int fail(pih_handle* h, const char* what, hipError_t e) {
 }
 #define HIPCHK(h, x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(h, #x, _e); } while (0)
 
+// Every entry point runs on the handle's own device ("one handle per device, handles independent"): the caller's current
+// device is switched for the duration of the call and restored afterwards.
+struct DevGuard {
+  int prev = -1; bool switched = false; hipError_t err = hipSuccess;
+  explicit DevGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+  }
+  ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define PIH_ENTER(h) DevGuard _guard((h)->device); if (_guard.err != hipSuccess) return fail(h, "select the handle's device", _guard.err)
+
 static Params make_params(const pih_config* c) {
   Params P;
   P.dt = c->dt; P.resid = c->residual_threshold; P.erp = c->erp; P.warm = c->warmstart; P.margin = c->contact_margin;
@@ -239,48 +256,34 @@ static Params make_params(const pih_config* c) {
   return P;
 }
 
+// fold finished event triples into the running sums (called when the pool is full and by pih_timing)
+static int drain_events(pih_handle* h) {
+  for (size_t i = 0; i < h->ev_used; i++) {
+    HIPCHK(h, hipEventSynchronize(h->ev[i].c));
+    float m1 = 0, m2 = 0;
+    HIPCHK(h, hipEventElapsedTime(&m1, h->ev[i].a, h->ev[i].b));
+    HIPCHK(h, hipEventElapsedTime(&m2, h->ev[i].b, h->ev[i].c));
+    h->acc_pre_ms += m1; h->acc_step_ms += m2; h->acc_n++;
+  }
+  h->ev_used = 0;
+  return 0;
+}
+
 extern "C" {
 
 void pih_default_config(pih_config* c) {
   memset(c, 0, sizeof *c);
   c->n_envs = 1; c->env_index0 = 0; c->mode = 0; c->solver_iters = 50; c->ik_iters = 20; c->max_episode_steps = 2227;
-  c->auto_reset = 0; c->enable_self_collision = 1; c->enable_arm_collision = 1; c->debug = 0; c->schedule = 1; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
+  c->auto_reset = 0; c->enable_self_collision = 1; c->enable_arm_collision = 1; c->task_id = PIH_TASK_PEG_IN_HOLE; c->debug = 0; c->schedule = 1; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
   c->erp = 0.2f; c->warmstart = 0.85f; c->contact_margin = 0.005f; c->linear_slop = 1e-5f; c->ik_damping = 0.5f; c->ik_residual = 1e-4f;
   c->dv = 2.0f / 240.0f;
 }
 int pih_abi_version(void) { return PIH_ABI_VERSION; }
 
-int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** out) {
-  if (!cfg || !out || cfg->n_envs <= 0) { g_err = "pih_create: bad arguments"; return -2; }
-  int ndev = 0;
-  hipError_t e = hipGetDeviceCount(&ndev);
-  if (e != hipSuccess || ndev == 0) { g_err = "pih_create: no HIP device (this library has no CPU path)"; return -3; }
-  pih_handle* h = new pih_handle;
-  h->cfg = *cfg; h->P = make_params(cfg);
-  HIPCHK(h, hipGetDevice(&h->device));
-  size_t nb = (size_t)cfg->n_envs * PIH_STATE_WORDS * sizeof(float);
-  HIPCHK(h, hipMalloc(&h->state, nb));
-  HIPCHK(h, hipMemset(h->state, 0, nb));
-  HIPCHK(h, hipMalloc(&h->ovf, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
-  if (cfg->schedule) HIPCHK(h, hipMalloc(&h->order, (size_t)cfg->n_envs * sizeof(int)));
-  if (cfg->debug) { HIPCHK(h, hipMalloc(&h->dbg, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); HIPCHK(h, hipMemset(h->dbg, 0, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); }
-  float* offd = nullptr;
-  if (offsets_host) {
-    HIPCHK(h, hipMalloc(&offd, (size_t)cfg->n_envs * 3 * sizeof(float)));
-    HIPCHK(h, hipMemcpy(offd, offsets_host, (size_t)cfg->n_envs * 3 * sizeof(float), hipMemcpyHostToDevice));
-  }
-  hipLaunchKernelGGL(pih_init_offsets_kernel, dim3((cfg->n_envs + 63) / 64), dim3(64), 0, 0, h->state, offd, cfg->n_envs);
-  hipLaunchKernelGGL(pih_reset_kernel, dim3(cfg->n_envs), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipDeviceSynchronize());
-  if (offd) hipFree(offd);
-  *out = h;
-  return 0;
-}
-
 int pih_destroy(pih_handle* h) {
   if (!h) return 0;
-  for (auto& p : h->ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  DevGuard guard(h->device);
+  for (auto& p : h->ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); hipEventDestroy(p.c); }
   if (h->state) hipFree(h->state);
   if (h->dbg) hipFree(h->dbg);
   if (h->ovf) hipFree(h->ovf);
@@ -289,28 +292,75 @@ int pih_destroy(pih_handle* h) {
   return 0;
 }
 
+// allocation + first reset; on any failure the caller (pih_create) destroys the half-built handle
+static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
+  const pih_config* cfg = &h->cfg;
+  size_t nb = (size_t)cfg->n_envs * PIH_STATE_WORDS * sizeof(float);
+  HIPCHK(h, hipMalloc(&h->state, nb));
+  HIPCHK(h, hipMemset(h->state, 0, nb));
+  HIPCHK(h, hipMalloc(&h->ovf, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
+  HIPCHK(h, hipMemset(h->ovf, 0, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
+  if (cfg->schedule) HIPCHK(h, hipMalloc(&h->order, (size_t)cfg->n_envs * sizeof(int)));
+  if (cfg->debug) { HIPCHK(h, hipMalloc(&h->dbg, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); HIPCHK(h, hipMemset(h->dbg, 0, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); }
+  if (offsets_host) {
+    HIPCHK(h, hipMalloc(offd, (size_t)cfg->n_envs * 3 * sizeof(float)));
+    HIPCHK(h, hipMemcpy(*offd, offsets_host, (size_t)cfg->n_envs * 3 * sizeof(float), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(pih_init_offsets_kernel, dim3((cfg->n_envs + 63) / 64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
+  hipLaunchKernelGGL(pih_reset_kernel, dim3(cfg->n_envs), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipDeviceSynchronize());
+  return 0;
+}
+
+int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** out) {
+  if (!cfg || !out || cfg->n_envs <= 0) { g_err = "pih_create: bad arguments"; return -2; }
+  if (cfg->task_id != PIH_TASK_PEG_IN_HOLE) { g_err = "pih_create: unknown task_id"; return -2; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) { g_err = "pih_create: no HIP device (this library has no CPU path)"; return -3; }
+  pih_handle* h = new pih_handle;
+  h->cfg = *cfg; h->P = make_params(cfg);
+  float* offd = nullptr;
+  int rc = -1;
+  if (hipGetDevice(&h->device) == hipSuccess) rc = create_impl(h, offsets_host, &offd);
+  else g_err = "pih_create: hipGetDevice failed";
+  if (offd) hipFree(offd);
+  if (rc != 0) { pih_destroy(h); return rc; }   // nothing leaks on the error path (g_err keeps the message)
+  *out = h;
+  return 0;
+}
+
 int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, void* stream) {
-  (void)hard;   // the reference reloads every URDF on reset regardless (envs/peg_in_hole.py:227-251)
   if (!h) return -2;
-  hipLaunchKernelGGL(pih_reset_kernel, dim3(h->cfg.n_envs), dim3(64), 0, (hipStream_t)stream, h->P, h->state, mask_dev);
+  PIH_ENTER(h);
+  hipLaunchKernelGGL(pih_reset_kernel, dim3(h->cfg.n_envs), dim3(64), 0, (hipStream_t)stream, h->P, h->state, mask_dev, hard != 0);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
 
+int pih_reseed(pih_handle* h, uint64_t seed) {
+  if (!h) return -2;
+  h->cfg.seed = seed; h->P.seed = seed;
+  return 0;
+}
+
 static int launch_step(pih_handle* h, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t s) {
-  hipLaunchKernelGGL(pih_pre_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  EvTriple* t = nullptr;
   if (h->timing) {
+    if (h->ev_used == EV_POOL) { int r = drain_events(h); if (r) return r; }
     if (h->ev_used == h->ev.size()) {
-      hipEvent_t a, b;
-      HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
-      h->ev.emplace_back(a, b);
+      EvTriple n;
+      HIPCHK(h, hipEventCreate(&n.a)); HIPCHK(h, hipEventCreate(&n.b)); HIPCHK(h, hipEventCreate(&n.c));
+      h->ev.push_back(n);
     }
-    e0 = h->ev[h->ev_used].first; e1 = h->ev[h->ev_used].second; h->ev_used++;
-    HIPCHK(h, hipEventRecord(e0, s));
+    t = &h->ev[h->ev_used++];
+    HIPCHK(h, hipEventRecord(t->a, s));
   }
+  hipLaunchKernelGGL(pih_pre_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs);
+  if (t) HIPCHK(h, hipEventRecord(t->b, s));
   hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, obs, reward, done, h->dbg, h->ovf, h->order);
-  if (h->timing) HIPCHK(h, hipEventRecord(e1, s));
+  if (t) HIPCHK(h, hipEventRecord(t->c, s));
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -318,18 +368,21 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
 int pih_step(pih_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
   if (!h) return -2;
   if (h->cfg.mode == 0 && !actions_dev) { h->err = "pih_step: actions_dev is NULL in action mode"; return -2; }
+  PIH_ENTER(h);
   return launch_step(h, actions_dev, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
 }
 
 int pih_step_n(pih_handle* h, int k, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
   if (!h || k < 0) return -2;
   if (h->cfg.mode == 0 && !actions_dev) { h->err = "pih_step_n: actions_dev is NULL in action mode"; return -2; }
+  PIH_ENTER(h);
   for (int i = 0; i < k; i++) { int r = launch_step(h, actions_dev, obs_dev, reward_dev, done_dev, (hipStream_t)stream); if (r) return r; }
   return 0;
 }
 
 int pih_get_state(pih_handle* h, int field, void* out_dev, void* stream) {
   if (!h || !out_dev) return -2;
+  PIH_ENTER(h);
   hipStream_t s = (hipStream_t)stream;
   const int n = h->cfg.n_envs;
   switch (field) {
@@ -349,12 +402,14 @@ int pih_get_state(pih_handle* h, int field, void* out_dev, void* stream) {
 int pih_set_state(pih_handle* h, int field, const void* in_dev, void* stream) {
   if (!h || !in_dev) return -2;
   if (field != PIH_FIELD_STATE) { h->err = "pih_set_state: only PIH_FIELD_STATE is writable"; return -2; }
+  PIH_ENTER(h);
   HIPCHK(h, hipMemcpyAsync(h->state, in_dev, (size_t)h->cfg.n_envs * PIH_STATE_WORDS * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 
 int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream) {
   if (!h || n <= 0 || !q0_dev || !tpos_dev || !tquat_dev || !qout_dev) return -2;
+  PIH_ENTER(h);
   hipLaunchKernelGGL(pih_ik_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, n, q0_dev, tpos_dev, tquat_dev, qout_dev);
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -362,6 +417,7 @@ int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, con
 
 int pih_ik_ur5(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream) {
   if (!h || n <= 0 || !q0_dev || !tpos_dev || !tquat_dev || !qout_dev) return -2;
+  PIH_ENTER(h);
   hipLaunchKernelGGL(pih_ik_ur5_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, n, q0_dev, tpos_dev, tquat_dev, qout_dev);
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -373,6 +429,7 @@ int pih_render(pih_handle* h, float* out_dev, int width, int height, int env_beg
     return -2;
   }
   if ((reinterpret_cast<uintptr_t>(out_dev) & 15) != 0) { h->err = "pih_render: out_dev must be 16-byte aligned"; return -2; }
+  PIH_ENTER(h);
   // every workgroup runs the forward kinematics of its env once: few strips per env when the batch alone gives the chip
   // several rounds of workgroups (>= 8192: images differ ~3x in cost, the tail matters), more strips for small batches
   int strips = (8192 + env_count - 1) / env_count;
@@ -391,6 +448,7 @@ int pih_grasp_labels(pih_handle* h, float* out_dev, float* meta_dev, int size, i
     if (h) h->err = "pih_grasp_labels: bad arguments";
     return -2;
   }
+  PIH_ENTER(h);
   hipLaunchKernelGGL(pih_labels_kernel, dim3((size * size + 1023) / 1024, env_count), dim3(256), 0, (hipStream_t)stream, h->state, out_dev, meta_dev, env_begin, size);
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -398,18 +456,23 @@ int pih_grasp_labels(pih_handle* h, float* out_dev, float* meta_dev, int size, i
 
 int pih_set_timing(pih_handle* h, int enable) { if (!h) return -2; h->timing = enable != 0; return 0; }
 
-int pih_timing(pih_handle* h, int reset, double* avg_ms_out, int64_t* launches_out) {
+int pih_timing2(pih_handle* h, int reset, double* pre_ms_out, double* step_ms_out, int64_t* launches_out) {
   if (!h) return -2;
-  double tot = 0;
-  for (size_t i = 0; i < h->ev_used; i++) {
-    HIPCHK(h, hipEventSynchronize(h->ev[i].second));
-    float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i].first, h->ev[i].second));
-    tot += ms;
-  }
-  if (avg_ms_out) *avg_ms_out = h->ev_used ? tot / (double)h->ev_used : 0.0;
-  if (launches_out) *launches_out = (int64_t)h->ev_used;
-  if (reset) h->ev_used = 0;
+  PIH_ENTER(h);
+  int r = drain_events(h);
+  if (r) return r;
+  if (pre_ms_out) *pre_ms_out = h->acc_n ? h->acc_pre_ms / (double)h->acc_n : 0.0;
+  if (step_ms_out) *step_ms_out = h->acc_n ? h->acc_step_ms / (double)h->acc_n : 0.0;
+  if (launches_out) *launches_out = h->acc_n;
+  if (reset) { h->acc_pre_ms = h->acc_step_ms = 0; h->acc_n = 0; }
   return 0;
+}
+
+int pih_timing(pih_handle* h, int reset, double* avg_ms_out, int64_t* launches_out) {
+  double a = 0, b = 0;
+  int r = pih_timing2(h, reset, &a, &b, launches_out);
+  if (r == 0 && avg_ms_out) *avg_ms_out = a + b;
+  return r;
 }
 
 const char* pih_last_error(pih_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }

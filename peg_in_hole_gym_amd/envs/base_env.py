@@ -25,6 +25,14 @@ def _to_numpy(x):
     return np.asarray(x)
 
 
+def _reset_backend(backend, hard_reset):
+    """BaseEnv.reset(hard_reset) (envs/base_env.py:84-94): hard = resetSimulation, here also a restart of the seed's scene sequence"""
+    try:
+        backend.reset(None, hard_reset=bool(hard_reset))
+    except TypeError:      # a backend without the keyword
+        backend.reset(None)
+
+
 def scripted_episode(backend, actions, n):
     """One reference step() in scripted mode = one whole random_grasp episode (envs/peg_in_hole.py:33-37,53-116): 2226
     physics steps.  get_info returns observation = the wrist-camera image taken when the state machine enters state 2
@@ -71,7 +79,7 @@ class BaseEnv(object):
 
     # --- reference API -------------------------------------------------------------------------------------------
     def reset(self, hard_reset=False):
-        self._backend.reset(None)
+        self._reset_backend(hard_reset)
         self.observations = self.observation_space.sample()
         self.rewards = [0. for _ in range(self.task_num)]
         self.infos = [{} for _ in range(self.task_num)]
@@ -106,6 +114,14 @@ class BaseEnv(object):
             self._backend.close()
 
     # --- helpers -------------------------------------------------------------------------------------------------
+    def _reset_backend(self, hard_reset):
+        _reset_backend(self._backend, hard_reset)
+
+    @property
+    def invalid(self):
+        """[task_num] bools: agents whose state became non-finite (re-initialised, reported done, frozen until reset)."""
+        return [bool(x) for x in _to_numpy(self._backend.invalid())]
+
     def _wrap_actions(self, a):
         try:
             import torch

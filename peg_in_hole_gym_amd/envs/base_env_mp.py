@@ -3,7 +3,7 @@ nesting (envs/base_env_mp.py:7-87).  The reference forks mp_num processes and pi
 Queue(1) pairs; here every agent is one wavefront of ONE batched launch, so there are no worker processes at all."""
 import numpy as np
 
-from .base_env import IMG_SHAPE, TASK_LIST, _MODES, _default_backend, _to_numpy, scripted_episode
+from .base_env import IMG_SHAPE, TASK_LIST, _MODES, _default_backend, _reset_backend, _to_numpy, scripted_episode
 from .utils import (MultiAgentActionSpace, MultiAgentObservationSpace, MPMultiAgentActionSpace,
                     MPMultiAgentObservationSpace, env_offsets)
 
@@ -40,11 +40,19 @@ class BaseEnvMp(object):
         kw.update(cfg)
         self._backend = factory(self.n, offs, **kw)
 
+    def _reset_backend(self, hard_reset):
+        _reset_backend(self._backend, hard_reset)
+
+    @property
+    def invalid(self):
+        """[mp_num][sub_num] bools: agents whose state became non-finite (re-initialised, reported done, frozen until reset)."""
+        return self._nest([bool(x) for x in _to_numpy(self._backend.invalid())])
+
     def _nest(self, flat):
         return [[flat[i * self.sub_num + j] for j in range(self.sub_num)] for i in range(self.mp_num)]
 
     def reset(self, hard_reset=False):
-        self._backend.reset(None)
+        self._reset_backend(hard_reset)
         self.observations = self.observation_space.sample()
         self.rewards = [[0. for _ in range(self.sub_num)] for _ in range(self.mp_num)]
         self.infos = [[{} for _ in range(self.sub_num)] for _ in range(self.mp_num)]

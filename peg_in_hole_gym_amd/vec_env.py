@@ -60,6 +60,14 @@ class PihVecEnv:
         with torch.cuda.device(self.device):
             self._chk(self.L.pih_reset(self.h, m.data_ptr() if m is not None else None, int(hard_reset), self._stream()), "pih_reset")
 
+    def reseed(self, seed):
+        """New base seed for later resets (env seed = seed + 1000 + global env index); use reset(hard_reset=True) to restart the draws."""
+        self._chk(self.L.pih_reseed(self.h, int(seed)), "pih_reseed")
+
+    def invalid(self):
+        """uint8-like [n]: envs whose state became non-finite with auto_reset = 0 (re-initialised, done, frozen until reset)."""
+        return self.state()[:, _lib.S_INVALID] != 0
+
     def step(self, actions):
         a = None
         if actions is not None:
@@ -152,7 +160,14 @@ class PihVecEnv:
         self.L.pih_set_timing(self.h, int(enable))
 
     def timing(self, reset=True):
+        """(average ms per step = controller/sort launch + physics launch, number of timed steps)"""
         ms = C.c_double(0)
         n = C.c_int64(0)
         self._chk(self.L.pih_timing(self.h, int(reset), C.byref(ms), C.byref(n)), "pih_timing")
         return ms.value, n.value
+
+    def timing2(self, reset=True):
+        """(average ms of pih_pre_kernel, average ms of pih_step_kernel, number of timed steps), HIP events on the launch stream"""
+        a = C.c_double(0); b = C.c_double(0); n = C.c_int64(0)
+        self._chk(self.L.pih_timing2(self.h, int(reset), C.byref(a), C.byref(b), C.byref(n)), "pih_timing2")
+        return a.value, b.value, n.value

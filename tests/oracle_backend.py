@@ -14,8 +14,14 @@ class OracleBackend:
         self.o = O.Oracle(n, offsets=self.offsets, **kw)
         self._obs = None
 
-    def reset(self, mask=None):
-        self.o.reset(None if mask is None else np.asarray(mask))
+    def reset(self, mask=None, hard_reset=False):
+        self.o.reset(None if mask is None else np.asarray(mask), hard_reset=hard_reset)
+
+    def reseed(self, seed):
+        self.o.reseed(seed)
+
+    def invalid(self):
+        return self.o.get_state()[:, 112] != 0
 
     def step(self, actions):
         a = np.asarray(actions, dtype=np.float64).reshape(self.n, 4)

@@ -1,0 +1,29 @@
+"""Shared constructed scenarios for the parity tests (test infrastructure)."""
+import numpy as np
+
+
+def coil_pipe_flat(s):
+    """Lay every env's pipe flat on the table as a planar spiral (only the z-axis joints are bent, tighter for higher env
+    indices): all 25 vertex spheres touch the table and the inner turns touch each other, so a step sees 25..~42 contacts,
+    i.e. the > 20 (global-scratch spill) and > 32 (third sign word) contact paths of the HIP PGS.  `s`: oracle state
+    [n, >= 98] (modified in place and returned)."""
+    n = s.shape[0]
+    for e in range(n):
+        s[e, 31:54] = 0
+        s[e, 31:54:2] = np.linspace(1.5, 0.5, 12) * (0.8 + 0.05 * (e % 8))
+        s[e, 20] = -0.04 + 1e-4
+        s[e, 25:31] = 0
+        s[e, 54:77] = 0
+    return s
+
+
+def stiff_finger_contact(contacts):
+    """True if the oracle's contact list ([k,12]: linkA linkB p n depth mu key lambda_n) holds a LOADED finger contact with the
+    clamped friction mu = 10 (finger pad on one of the pipe's 11-gram end links, URDF friction 100): with pyramid friction that
+    large PGS is not a contraction, so rounding differences between two implementations are amplified within one step
+    (the fp64 build of the product algorithm shows the same against the fp64 oracle)."""
+    c = np.asarray(contacts)
+    if len(c) == 0:
+        return False
+    finger = (c[:, 1] >= 7) & (c[:, 1] <= 8)
+    return bool((finger & (c[:, 9] >= 10.0) & (c[:, 11] > 0)).any())

@@ -173,3 +173,53 @@ def test_joint_limit_rows_f64(oracle_mod):
         if t == 0:
             assert abs(se[0, 11] - 4.8) < 1e-4 and abs(se[1, 12] - 2.4) < 1e-4
     assert abs(se[0, 2] - 2.9671) < 1e-5 and abs(se[1, 3]) < 1e-5
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_many_contacts_spill_rows(oracle_mod, prec):
+    """> 20 and > 32 simultaneous contacts (rows / records of contacts 21..48 live in the global spill area): pipes coiled flat
+    on the table, gripper coming down on the coil (scripted mode).  Contact keys, per-contact normal impulse, pose and force
+    against the oracle, resynchronised every checked step; the counts reached are asserted.  Steps with a loaded mu = 10
+    finger contact (ill-conditioned for PGS, tests/scenarios.py) are reported separately."""
+    from tests.scenarios import coil_pipe_flat, stiff_finger_contact
+    N = 4
+    kw = dict(mode=1, dv=0.05, residual_threshold=0.0, warmstart=0.0)
+    o = oracle_mod.Oracle(N, **kw); e = E.Emul(N, prec, debug=1, **kw)
+    s0 = oracle_mod.Oracle(8, **kw).get_state()
+    o.set_state(coil_pipe_flat(s0)[4:8])
+    a = np.zeros((N, 4))
+    seen = np.zeros(49, int); perr, ferr, lerr, stiff = [], [], [], []
+    for t in range(1100):
+        check = t < 40 or 640 <= t < 700 or 1021 <= t < 1100
+        if check:
+            so = o.get_state(); se = e.get_state(); se[:, :98] = so[:, :98]; se[:, 128] = 0; e.set_state(se)
+        o.step(a)
+        if not check:
+            continue
+        e.step(a)
+        so = o.get_state(); se = e.get_state()
+        nco = o.ncontacts()
+        np.testing.assert_array_equal(nco, se[:, 106].astype(int))
+        dbg = e.get_debug()
+        for i in range(N):
+            oc = o.debug_contacts(i); k = len(oc)
+            gc = dbg[i, 40:40 + 12 * k].reshape(k, 12)
+            np.testing.assert_array_equal(oc[:, 10], gc[:, 10])
+            st = stiff_finger_contact(oc); stiff.append(st)
+            if not st:
+                seen[k] += 1
+            lerr.append(np.abs(oc[:, 11] - gc[:, 11]).max() / (1e-3 + np.abs(oc[:, 11]).max()))
+        perr.append(np.abs(so[:, POS] - se[:, POS]).max(1))
+        cf = o.contact_force(); ferr.append(np.abs(se[:, 105] - cf) / (1 + np.abs(cf)))
+    perr = np.concatenate(perr); ferr = np.concatenate(ferr); lerr = np.array(lerr); stiff = np.array(stiff)
+    ok = ~stiff
+    print(prec, "well-conditioned env-steps: max contacts", seen.nonzero()[0].max(), ">20:", seen[21:].sum(), ">32:", seen[33:].sum(),
+          "pose p50/p99/max %.2e %.2e %.2e force %.2e %.2e %.2e lam %.2e %.2e | stiff env-steps %d: pose p50 %.2e max %.2e" % (
+              np.percentile(perr[ok], 50), np.percentile(perr[ok], 99), perr[ok].max(), np.percentile(ferr[ok], 50), np.percentile(ferr[ok], 99),
+              ferr[ok].max(), np.percentile(lerr[ok], 50), np.percentile(lerr[ok], 99), stiff.sum(), np.percentile(perr[stiff], 50), perr[stiff].max()))
+    assert seen[21:].sum() > 150 and seen[33:].sum() > 50
+    if prec == "f64":
+        assert perr[ok].max() < 1e-7 and ferr[ok].max() < 1e-5 and lerr[ok].max() < 1e-5
+    else:
+        assert np.percentile(perr[ok], 50) < 5e-6 and np.percentile(perr[ok], 99) < 1e-4
+        assert np.percentile(ferr[ok], 50) < 1e-3 and np.percentile(ferr[ok], 99) < 1e-2

@@ -40,6 +40,48 @@ def test_masked_reset_and_state_roundtrip(torch_mod):
     assert torch.equal(g.state(), s1)
 
 
+def test_hard_reset_reseed_and_two_handles(torch_mod):
+    """pih_reset(hard=1) restarts the env's draw sequence, pih_reseed changes it; two live handles in one process do not
+    disturb each other (every entry point selects its handle's device and restores the caller's)."""
+    torch = torch_mod
+    n = 33
+    a = _gpu(n, seed=4); b = _gpu(n, seed=4)
+    first = a.state().clone()
+    act = torch.rand(n, 4, device="cuda") * 2 - 1
+    for _ in range(5):
+        a.step(act); b.step(act)                     # interleaved launches on two handles
+    assert torch.equal(a.state(), b.state())
+    a.reset()                                         # soft reset: a NEW scene (counter continues)
+    assert not torch.equal(a.state()[:, 18:20], first[:, 18:20])
+    a.reset(hard_reset=True)                          # hard reset: the first scene again, bit for bit
+    assert torch.equal(a.state()[:, :98], first[:, :98])
+    a.reseed(77); a.reset(hard_reset=True)
+    c = _gpu(n, seed=77)
+    assert torch.equal(a.state()[:, :98], c.state()[:, :98]) and not torch.equal(a.state()[:, 18:20], first[:, 18:20])
+    assert torch.equal(b.state()[:, 93], torch.full((n,), 5.0, device="cuda"))     # b was never touched by a's resets
+
+
+def test_non_finite_env_is_frozen_and_flagged(torch_mod):
+    """auto_reset = 0 (the facade's setting): an env whose state turns non-finite is re-initialised, reported done, flagged
+    invalid and then stays frozen -- it does not silently start a second episode."""
+    torch = torch_mod
+    n = 8
+    g = _gpu(n, seed=1)
+    s = g.state().clone(); s[2, 18] = float("nan"); s[5, 54] = float("inf"); g.set_state(s)
+    a = torch.zeros(n, 4, device="cuda")
+    _, _, done = g.step(a)
+    st = g.state()
+    assert done.cpu().tolist() == [0, 0, 1, 0, 0, 1, 0, 0]
+    assert torch.isfinite(st).all() and g.invalid().cpu().tolist() == [False, False, True, False, False, True, False, False]
+    assert (st[[2, 5], 97] == 1).all() and (st[[2, 5], 88] == 1).all()
+    frozen = st[[2, 5]].clone()
+    for _ in range(3):
+        _, _, done = g.step(a)
+    assert torch.equal(g.state()[[2, 5], :98], frozen[:, :98]) and done[[2, 5]].all()
+    g.reset()
+    assert not g.invalid().any()
+
+
 def test_step_n_equals_repeated_step(torch_mod):
     torch = torch_mod
     n = 64
@@ -73,8 +115,12 @@ def test_timing_api_and_obs_fields(torch_mod):
     g.set_timing(True)
     for _ in range(5):
         obs, rew, done = g.step(a)
-    ms, k = g.timing()
-    assert k == 5 and 0 < ms < 50
+    ms, k = g.timing(reset=False)
+    pre, phys, k2 = g.timing2()
+    assert k == 5 and k2 == 5 and 0 < ms < 50 and pre > 0 and phys > pre and abs(pre + phys - ms) < 1e-9
+    for _ in range(1100):                        # more timed launches than the event pool holds: folded into running sums
+        g.step(a)
+    assert g.timing()[1] == 1100
     torch.cuda.synchronize()
     st = g.state()
     assert torch.allclose(obs[:, 2:5], g.ee_position()) and torch.allclose(obs[:, 0:2], st[:, 7:9])

@@ -34,7 +34,7 @@ def test_native_library_loaded(torch_mod):
     import ctypes
     from peg_in_hole_gym_amd import _lib
     L = _lib.load()
-    assert isinstance(L, ctypes.CDLL) and L.pih_abi_version() == 2
+    assert isinstance(L, ctypes.CDLL) and L.pih_abi_version() == 3
 
 
 def test_reset_matches_oracle(torch_mod, oracle_mod):
@@ -69,10 +69,12 @@ def test_one_step_parity_resynchronised(torch_mod, oracle_mod):
     g = _gpu(N, residual_threshold=0.0, warmstart=0.0, debug=1)
     rng = np.random.default_rng(0)
     perr, ferr = [], []
+    hist = np.zeros(49, int)
     for t in range(300):
         a = rng.uniform(-1, 1, (N, 4))
         _to_gpu_state(torch, g, o.get_state())
         oo, ro, do = o.step(a)
+        np.add.at(hist, o.ncontacts(), 1)
         og, rg, dg = g.step(torch.tensor(a, dtype=torch.float32))
         so = o.get_state(); sg = g.state().cpu().numpy().astype(np.float64)
         ud = np.array([o.debug_udot(i) for i in range(N)])
@@ -86,8 +88,94 @@ def test_one_step_parity_resynchronised(torch_mod, oracle_mod):
     perr = np.concatenate(perr); ferr = np.concatenate(ferr)
     print("one-step pose err p50/p99/max = %.2e / %.2e / %.2e ; force rel err p50/p99/max = %.2e / %.2e / %.2e" % (
         np.percentile(perr, 50), np.percentile(perr, 99), perr.max(), np.percentile(ferr, 50), np.percentile(ferr, 99), ferr.max()))
+    print("contact-count histogram (env-steps per count):", hist[:hist.nonzero()[0].max() + 1].tolist())
+    # both sides of the merged first response pass (MERGED_CONTACTS = 10: <= 10 contacts take one sweep, 11 take two)
+    assert hist[10] > 20 and hist[11] > 20 and hist[9] > 20 and hist[12] > 20
     assert np.percentile(perr, 50) < 5e-6 and np.percentile(perr, 99) < 1e-4
     assert np.percentile(ferr, 50) < 1e-3 and np.percentile(ferr, 99) < 1e-2
+
+
+@pytest.mark.parametrize("N,steps", [(1, 400), (1024, 90)])
+def test_one_step_parity_config_sizes(torch_mod, oracle_mod, N, steps):
+    """BASELINE configs[0] shape (N = 1) and configs[1] (N = 1024): random-action rollout from reset, GPU resynchronised to the
+    oracle before every step; contact sets / done flags equal, pose and force error percentiles as in the N = 32 test."""
+    torch = torch_mod
+    o = oracle_mod.Oracle(N, omp=N > 64, residual_threshold=0.0, warmstart=0.0, seed=21)
+    g = _gpu(N, residual_threshold=0.0, warmstart=0.0, seed=21)
+    rng = np.random.default_rng(3)
+    perr, ferr = [], []
+    maxc = 0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (N, 4))
+        _to_gpu_state(torch, g, o.get_state())
+        oo, ro, do = o.step(a)
+        og, rg, dg = g.step(torch.tensor(a, dtype=torch.float32))
+        so = o.get_state(); sg = g.state().cpu().numpy().astype(np.float64)
+        np.testing.assert_array_equal(o.ncontacts(), sg[:, 106].astype(int))
+        np.testing.assert_array_equal(dg.cpu().numpy(), do)
+        np.testing.assert_allclose(og.cpu().numpy()[:, 2:], oo[:, 2:], atol=1e-4)
+        maxc = max(maxc, int(o.ncontacts().max()))
+        perr.append(np.abs(so[:, POS] - sg[:, POS]).max(1))
+        cf = o.contact_force(); ferr.append(np.abs(sg[:, 105] - cf) / (1 + np.abs(cf)))
+    perr = np.concatenate(perr); ferr = np.concatenate(ferr)
+    print("N=%d: max contacts %d; one-step pose err p50/p99/max = %.2e / %.2e / %.2e ; force rel err p50/p99/max = %.2e / %.2e / %.2e" % (
+        N, maxc, np.percentile(perr, 50), np.percentile(perr, 99), perr.max(), np.percentile(ferr, 50), np.percentile(ferr, 99), ferr.max()))
+    assert maxc >= 8
+    assert np.percentile(perr, 50) < 5e-6 and np.percentile(perr, 99) < 1e-4
+    assert np.percentile(ferr, 50) < 1e-3 and np.percentile(ferr, 99) < 1e-2
+
+
+def test_spill_path_many_contacts(torch_mod, oracle_mod):
+    """Contacts 21..48 take the global-scratch path of the HIP PGS (second `block` instantiation, sign words sg1 / sg2).
+    Pipes coiled flat on the table (25 table + up to ~17 self contacts) in scripted mode, so that the gripper later comes
+    down on the coil and closes (finger / arm contacts at slots >= 25): GPU resynchronised to the oracle before every checked
+    step; contact count, contact keys, link pairs, points / normals, per-contact normal impulse, pose and contact force are
+    compared and the counts the test reached are ASSERTED (> 20 and > 32).  Env-steps with a loaded mu = 10 finger contact
+    (ill-conditioned for PGS in any precision, tests/scenarios.py) are reported separately."""
+    torch = torch_mod
+    from tests.scenarios import coil_pipe_flat, stiff_finger_contact
+    N = 8
+    kw = dict(mode=1, dv=0.05, residual_threshold=0.0, warmstart=0.0)
+    o = oracle_mod.Oracle(N, **kw); g = _gpu(N, debug=1, **kw)
+    o.set_state(coil_pipe_flat(o.get_state()))
+    a = np.zeros((N, 4)); at = torch.zeros(N, 4)
+    perr, ferr, lerr, stiff = [], [], [], []
+    seen = np.zeros(49, int); arm_spilled = 0
+    for t in range(1150):
+        check = t < 40 or 600 <= t < 760 or 1015 <= t < 1150
+        if check:
+            _to_gpu_state(torch, g, o.get_state())
+        o.step(a)
+        if not check:
+            continue
+        g.step(at)
+        so = o.get_state(); sg = g.state().cpu().numpy().astype(np.float64)
+        nco = o.ncontacts()
+        np.testing.assert_array_equal(nco, sg[:, 106].astype(int))
+        dbg = g.debug().cpu().numpy().astype(np.float64)
+        for e in range(N):
+            oc = o.debug_contacts(e); k = len(oc)
+            gc = dbg[e, 40:40 + 12 * k].reshape(k, 12)
+            np.testing.assert_array_equal(oc[:, 10], gc[:, 10])                      # same contact keys, same order
+            np.testing.assert_array_equal(oc[:, 0:2], gc[:, 0:2])                    # same link pairs
+            np.testing.assert_allclose(oc[:, 2:9], gc[:, 2:9], atol=2e-5)            # point, normal, depth
+            st = stiff_finger_contact(oc); stiff.append(st)
+            if not st:
+                seen[k] += 1
+                arm_spilled += int(((oc[20:, 0] < 9) | ((oc[20:, 1] >= 0) & (oc[20:, 1] < 9))).sum())
+            lerr.append(np.abs(oc[:, 11] - gc[:, 11]).max() / (1e-3 + np.abs(oc[:, 11]).max()) if k else 0.0)
+        perr.append(np.abs(so[:, POS] - sg[:, POS]).max(1))
+        cf = o.contact_force(); ferr.append(np.abs(sg[:, 105] - cf) / (1 + np.abs(cf)))
+    perr = np.concatenate(perr); ferr = np.concatenate(ferr); lerr = np.array(lerr); stiff = np.array(stiff); ok = ~stiff
+    print("spill path, well-conditioned env-steps: max contacts %d, with > 20 contacts %d, with > 32 contacts %d, arm-involving contacts in spilled slots %d" % (
+        seen.nonzero()[0].max(), seen[21:].sum(), seen[33:].sum(), arm_spilled))
+    print("spill path: one-step pose err p50/p99/max = %.2e / %.2e / %.2e ; force rel err p50/p99/max = %.2e / %.2e / %.2e ; lambda_n rel err p50/p99 = %.2e / %.2e ; stiff env-steps %d: pose p50 %.2e" % (
+        np.percentile(perr[ok], 50), np.percentile(perr[ok], 99), perr[ok].max(), np.percentile(ferr[ok], 50), np.percentile(ferr[ok], 99), ferr[ok].max(),
+        np.percentile(lerr[ok], 50), np.percentile(lerr[ok], 99), stiff.sum(), np.percentile(perr[stiff], 50) if stiff.any() else 0.0))
+    assert seen[21:].sum() > 300 and seen[33:].sum() > 100 and arm_spilled > 50
+    assert np.percentile(perr[ok], 50) < 5e-6 and np.percentile(perr[ok], 99) < 1e-4
+    assert np.percentile(ferr[ok], 50) < 1e-3 and np.percentile(ferr[ok], 99) < 1e-2
+    assert np.percentile(lerr[ok], 50) < 2e-3 and np.percentile(lerr[ok], 99) < 5e-2
 
 
 @pytest.mark.parametrize("bent", [False, True])
