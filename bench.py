@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the vectorised peg-in-hole step on MI355X (BASELINE.json metric).
 
-One "step" = one pih_step launch = one dt = 1/240 s physics step (action -> IK -> motor targets -> collision -> ABA ->
+One "step" = one pih_step call = one dt = 1/240 s physics step (action -> IK -> motor targets -> collision -> ABA ->
 constraint rows -> PGS -> integrate -> obs/reward/done, auto-reset on done) of EVERY env of this rank.
 Workload (BASELINE.json configs[2], the one the >= 1 M env-steps/s target is quoted on): 4096 Panda peg-in-hole envs per
 GPU, random actions U(-1,1) generated on device before the timed region (torch.Generator seed 1234), env seeds 1000+i,
-dt 1/240, auto-reset.  N > 1: one process per GPU (torchrun), envs block-partitioned (weak scaling: 4096 per GPU), the
-stacked observation all-gathered over RCCL each step.
+dt 1/240, auto-reset.  The envs are PRE-ROLLED to contact steady state (--preroll, default 300 untimed steps after reset: the
+pipes have landed, the grippers wander at table height) before --warmup and the timed --steps, so that a short run measures
+the same contact load as a long one (`sanity.mean_contacts` is the average over the start and the end of the timed region).
+
+N GPUs: `python bench.py --gpus N` with WORLD_SIZE unset starts N ranks itself (torch.distributed.run, before anything touches
+the GPU) and relays rank 0's JSON line; under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  One process per GPU, envs
+block-partitioned, the stacked observation all-gathered over RCCL each step.  Default = weak scaling
+(--envs per GPU); --total-envs T fixes the whole job (BASELINE configs[3]: 16384 = 8 x 2048) and reports "strong".
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = 828 algorithmic bytes per env-step x envs per launch
-/ average step-kernel duration measured with HIP events on the launch stream (pih_timing).  `cpu_baseline` = the fp64
-oracle (CPU restatement, NOT PyBullet: PyBullet is not installable here) timed on this box's host cores on a bounded
-sample of the same workload.
+/ average pih_step_kernel duration measured with HIP events on the launch stream (pih_timing2; the controller/sort
+pre-kernel is reported next to it).  `cpu_baseline` = the CPU restatement in oracle/ ("port": NOT PyBullet, which is not
+installable here) built -O3 -march=native on this box and timed on its host cores on a bounded, pre-rolled sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,8 +34,16 @@ if ROOT not in sys.path:
 
 ALG_BYTES_PER_ENV_STEP = 828          # 98 state words R+W + action 16 + obs 20 + reward 4 + done 4
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
-FLOP_PER_ENV_STEP_EST = 1.4e6         # SURVEY.md 8d estimate (reported as context only)
 FP32_VECTOR_PEAK_TFLOPS = 157.3
+
+
+def counted_flops():
+    """fp32 operations per env-step counted on the device algorithm (profiles/flops_latest.json, written by
+    tools/count_flops.py from an instrumented host build of the step); None until that file exists."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "flops_latest.json")))
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def pmc_traffic(n_envs):
@@ -43,24 +60,83 @@ def pmc_traffic(n_envs):
     return None, None
 
 
-def cpu_baseline(envs_sample=4096, steps=24):
-    """Oracle ("port") on the host cores, all threads, bounded sample: envs_sample envs x steps steps."""
+def cpu_baseline(preroll=300, budget_s=25.0):
+    """CPU restatement ("port", oracle/) on this box's host cores, built here with -O3 -march=native.  Rows:
+    fp32 and fp64 with OpenMP over envs on all cores (pre-rolled to the same contact steady state as the GPU run), and the
+    reference's own shape -- N = 1 env, 1 thread, 1000 random-action steps from reset (BASELINE configs[0]).  `value` is the
+    fp32 all-cores row.  The sample is sized from a short probe so that the leg stays within ~budget_s."""
     import numpy as np
     from oracle import oracle as O
-    O.build()
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    o = O.Oracle(envs_sample, omp=True, auto_reset=1, max_episode_steps=2227)
+    outdir = tempfile.mkdtemp(prefix="pih_oracle_native_")
+    p64, p32 = O.build_native(outdir)
     rng = np.random.default_rng(1234)
-    acts = rng.uniform(-1, 1, (steps + 5, envs_sample, 4))
-    for t in range(5):        # warm-up (the pipes are still in free fall here: cheapest steps, like the GPU run's start)
-        o.step(acts[t])
+    rows = []
+
+    def run(path, n, pre, steps, label, threads):
+        o = O.Oracle(n, lib_path=path, auto_reset=1, max_episode_steps=2227)
+        acts = rng.uniform(-1, 1, (64, n, 4))
+        for t in range(pre):
+            o.step(acts[t % 64])
+        c0 = float(o.ncontacts().mean())
+        t0 = time.perf_counter()
+        for t in range(steps):
+            o.step(acts[(pre + t) % 64])
+        dt = time.perf_counter() - t0
+        c1 = float(o.ncontacts().mean())
+        rows.append({"label": label, "value": n * steps / dt, "unit": "env-steps/s", "envs": n, "steps": steps, "preroll": pre,
+                     "threads": threads, "mean_contacts": 0.5 * (c0 + c1)})
+        return rows[-1]
+
+    # probe: how fast is this box?  (32 envs per core, 20 steps from reset, fp32)
+    probe_n = 32 * cores
+    o = O.Oracle(probe_n, lib_path=p32, auto_reset=1)
+    a = rng.uniform(-1, 1, (probe_n, 4))
     t0 = time.perf_counter()
-    for t in range(steps):
-        o.step(acts[5 + t])
-    dt = time.perf_counter() - t0
-    return {"value": envs_sample * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d steps, fp64 oracle (CPU restatement, not PyBullet), OpenMP over envs" % (envs_sample, steps)}
+    for _ in range(20):
+        o.step(a)
+    rate = probe_n * 20 / (time.perf_counter() - t0)          # free-fall steps: an upper bound of the steady-state rate
+    del o
+    # all-cores rows: envs so that (preroll + timed) fits the budget at ~rate/2 (contact steps cost ~2x free-fall ones)
+    timed = 60
+    n = int(max(4 * cores, min(4096, (0.35 * budget_s * rate / 2) / (preroll + timed))))
+    n -= n % cores
+    main = run(p32, n, preroll, timed, "fp32 -O3 -march=native, OpenMP over envs, %d threads" % cores, cores)
+    run(p64, n, preroll, timed, "fp64 -O3 -march=native, OpenMP over envs, %d threads" % cores, cores)
+    # the reference's own configuration shape: one env, one thread, 1000 random-action steps from reset
+    os.environ["OMP_NUM_THREADS"] = "1"
+    try:
+        import ctypes
+        for path in (p32, p64):
+            try:
+                ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+            except Exception:  # noqa: BLE001
+                pass
+            run(path, 1, 0, 1000, "%s -O3 -march=native, N = 1 env, 1 thread, 1000 steps from reset (BASELINE configs[0] shape)" % ("fp32" if path == p32 else "fp64"), 1)
+    finally:
+        try:
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+        except Exception:  # noqa: BLE001
+            pass
+    return {"value": main["value"], "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d steps after a %d-step pre-roll to contact steady state (mean contacts %.1f), fp32 build of the CPU "
+                      "restatement in oracle/ (NOT PyBullet), gcc -O3 -march=native, OpenMP over envs on all %d cores" % (n, timed, preroll, main["mean_contacts"], cores),
+            "rows": rows}
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run BEFORE this process
+    touches the GPU, relay their output, exit with their code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -68,102 +144,145 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--preroll", type=int, default=300, help="untimed steps after reset, before --warmup: brings every env to contact steady state")
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (weak scaling)")
+    ap.add_argument("--total-envs", type=int, default=0, help="fix the whole job instead (strong scaling), e.g. 16384 = BASELINE configs[3]")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--mode", default="action", choices=["action", "scripted"], help="action = panda_execute per step (headline); scripted = the reference's grasp-and-insert state machine")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (1-GPU box, gloo backend)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / collective / JSON plumbing only, no env and no GPU (CPU test of the N>1 path)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+
     import torch
-    from peg_in_hole_gym_amd.vec_env import PihVecEnv
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    use_gpu = not args.dry_run
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.share_device:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+        if args.backend == "nccl" and use_gpu:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+            dist.init_process_group(backend="gloo" if not use_gpu else args.backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank if world > 1 else 0) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(dev)
 
-    n = args.envs
-    mode_kw = dict(mode=1, dv=0.05) if args.mode == "scripted" else {}
-    env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, max_episode_steps=2227, seed=args.seed, **mode_kw)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    pool = min(args.steps + args.warmup, 1024)
-    actions = torch.rand(pool, n, 4, device=dev, generator=gen) * 2 - 1       # resident in HBM before the timed region
+    if args.total_envs:
+        if args.total_envs % world:
+            raise SystemExit("--total-envs %d is not a multiple of the world size %d" % (args.total_envs, world))
+        n = args.total_envs // world
+        scaling = "strong"
+    else:
+        n = args.envs
+        scaling = "weak"
+
+    def sync():
+        if use_gpu:
+            torch.cuda.synchronize(dev)
+
+    env = None
+    if use_gpu:
+        from peg_in_hole_gym_amd.vec_env import PihVecEnv
+        mode_kw = dict(mode=1, dv=0.05) if args.mode == "scripted" else {}
+        env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, max_episode_steps=2227, seed=args.seed, **mode_kw)
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        pool = min(args.steps + args.warmup + args.preroll, 1024)
+        actions = torch.rand(pool, n, 4, device=dev, generator=gen) * 2 - 1       # resident in HBM before the timed region
+    local_obs = torch.zeros(n, 5, device=dev)
     gathered = torch.empty(world * n, 5, device=dev) if world > 1 and not args.no_allgather else None
 
     def one_step(t):
-        obs, rew, done = env.step(actions[t % pool])
+        obs = env.step(actions[t % pool])[0] if env is not None else local_obs
         if gathered is not None:
             dist.all_gather_into_tensor(gathered, obs)
 
-    for t in range(args.warmup):
+    def contacts():
+        return float(env.state()[:, 106].mean().item()) if env is not None else 0.0
+
+    for t in range(args.preroll + args.warmup):
         one_step(t)
-    torch.cuda.synchronize(dev)
-    env.set_timing(True)
-    env.timing(reset=True)
+    sync()
+    c_start = contacts()
+    if env is not None:
+        env.set_timing(True)
+        env.timing2(reset=True)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     for t in range(args.steps):
-        one_step(args.warmup + t)
-    torch.cuda.synchronize(dev)
+        one_step(args.preroll + args.warmup + t)
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = env.timing(reset=True)
-    env.set_timing(False)
+    pre_ms = kernel_ms = 0.0
+    launches = 0
+    if env is not None:
+        pre_ms, kernel_ms, launches = env.timing2(reset=True)
+        env.set_timing(False)
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    st = env.state()
-    finite = bool(torch.isfinite(st).all().item())
-    mean_contacts = float(st[:, 106].mean().item())
-    mean_iters = float(st[:, 107].mean().item())
+    finite = True
+    c_end = mean_iters = 0.0
+    if env is not None:
+        st = env.state()
+        finite = bool(torch.isfinite(st).all().item())
+        c_end = float(st[:, 106].mean().item())
+        mean_iters = float(st[:, 107].mean().item())
 
     if rank == 0:
         total_envs = n * world
-        value = total_envs * args.steps / elapsed
+        value = total_envs * args.steps / elapsed if not args.dry_run else None
         achieved = ALG_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, traffic_detail = pmc_traffic(n)
+        fl = counted_flops()
+        note = "latency/VALU/LDS-bound path (SURVEY.md 0.6): HBM fraction is ~0 by construction"
+        if fl and kernel_ms > 0:
+            tf = fl["flop_per_env_step"] * n / (kernel_ms * 1e-3) / 1e12
+            note += "; counted %.0f fp32 flop per env-step (%s) -> %.2f TFLOP/s = %.2f%% of the fp32 vector peak" % (
+                fl["flop_per_env_step"], fl.get("source", "profiles/flops_latest.json"), tf, 100 * tf / FP32_VECTOR_PEAK_TFLOPS)
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Panda peg-in-hole, %d parallel envs per GPU, %s, dt=1/240, auto-reset" % (n, "random actions U(-1,1)" if args.mode == "action" else "scripted grasp-and-insert episodes"),
-                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + %s all-gather(obs)" % ("RCCL" if args.backend == "nccl" else args.backend))},
+            "config": {"workload": "Panda peg-in-hole, %d parallel envs per GPU, %s, dt=1/240, auto-reset, pre-rolled %d steps to contact steady state" % (
+                           n, "random actions U(-1,1)" if args.mode == "action" else "scripted grasp-and-insert episodes", args.preroll),
+                       "envs_per_gpu": n, "total_envs": total_envs, "preroll": args.preroll,
+                       "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + %s all-gather(obs)" % ("RCCL" if args.backend == "nccl" and use_gpu else "gloo"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (ALG_BYTES_PER_ENV_STEP * n),
-                         "kernel": "pih_step_kernel", "kernel_avg_ms": kernel_ms, "launches": launches,
-                         "alg_bytes_per_env_step": ALG_BYTES_PER_ENV_STEP,
-                         "note": "latency/VALU/LDS-bound path (SURVEY.md 0.6): HBM fraction is ~0 by construction; "
-                                 "est. %.2f TFLOP/s = %.2f%% of fp32 vector peak" % (FLOP_PER_ENV_STEP_EST * n / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0,
-                                                                                      100 * FLOP_PER_ENV_STEP_EST * n / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS if kernel_ms > 0 else 0.0)},
-            "sanity": {"state_finite": finite, "mean_contacts": mean_contacts, "mean_pgs_iters": mean_iters},
+                         "kernel": "pih_step_kernel", "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches,
+                         "alg_bytes_per_env_step": ALG_BYTES_PER_ENV_STEP, "note": note},
+            "sanity": {"state_finite": finite, "mean_contacts": 0.5 * (c_start + c_end), "mean_contacts_start": c_start, "mean_contacts_end": c_end,
+                       "mean_pgs_iters": mean_iters},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if args.dry_run:
+            out["dry_run"] = True
+        if not args.no_cpu_baseline and world == 1 and not args.dry_run:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(preroll=args.preroll)
             except Exception as ex:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (ex,)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

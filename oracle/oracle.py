@@ -14,12 +14,18 @@ CMAX = 48
 NDOF = 38
 
 
-class Config(C.Structure):
-    _fields_ = [("n_envs", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32), ("ik_iters", C.c_int32),
-                ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("enable_self_collision", C.c_int32),
-                ("env_index0", C.c_int32), ("enable_arm_collision", C.c_int32), ("seed", C.c_uint64), ("dt", C.c_double), ("residual_threshold", C.c_double),
-                ("erp", C.c_double), ("warmstart", C.c_double), ("contact_margin", C.c_double), ("linear_slop", C.c_double),
-                ("ik_damping", C.c_double), ("ik_residual", C.c_double), ("dv", C.c_double)]
+def _config_type(real):
+    class _Config(C.Structure):
+        _fields_ = [("n_envs", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32), ("ik_iters", C.c_int32),
+                    ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("enable_self_collision", C.c_int32),
+                    ("env_index0", C.c_int32), ("enable_arm_collision", C.c_int32), ("seed", C.c_uint64), ("dt", real), ("residual_threshold", real),
+                    ("erp", real), ("warmstart", real), ("contact_margin", real), ("linear_slop", real),
+                    ("ik_damping", real), ("ik_residual", real), ("dv", real)]
+    return _Config
+
+
+Config = _config_type(C.c_double)      # piho_config of the fp64 (checker) builds
+ConfigF32 = _config_type(C.c_float)    # ... of the fp32 CPU-baseline build (PIHO_REAL=float)
 
 
 def build(force=False):
@@ -31,16 +37,27 @@ def build(force=False):
 _libs = {}
 
 
-def lib(omp=False):
-    name = "libpih_oracle_omp.so" if omp else "libpih_oracle.so"
+def build_native(outdir):
+    """-O3 -march=native -fopenmp builds (fp64 and fp32) for bench.py's cpu_baseline, compiled ON the box that times them
+    into `outdir` (never in-tree: a -march=native object built in one container must not travel to another CPU)."""
+    subprocess.check_call(["make", "-C", _DIR, "-s", "native", "OUT=" + os.path.abspath(outdir)])
+    return os.path.join(outdir, "libpih_oracle_f64_native.so"), os.path.join(outdir, "libpih_oracle_f32_native.so")
+
+
+def lib(omp=False, path=None):
+    name = path or ("libpih_oracle_omp.so" if omp else "libpih_oracle.so")
     if name not in _libs:
-        path = os.path.join(_DIR, name)
+        path = path or os.path.join(_DIR, name)
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
-        dp = C.POINTER(C.c_double)
+        L.piho_real_bytes.restype = C.c_int
+        f32 = L.piho_real_bytes() == 4
+        dp = C.POINTER(C.c_float if f32 else C.c_double)
+        L._np_real = np.float32 if f32 else np.float64
+        L._cfg_type = ConfigF32 if f32 else Config
         L.piho_create.restype = C.c_void_p
-        L.piho_create.argtypes = [C.POINTER(Config), dp]
+        L.piho_create.argtypes = [C.POINTER(L._cfg_type), dp]
         L.piho_destroy.argtypes = [C.c_void_p]
         L.piho_reset.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         L.piho_reset_hard.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
@@ -59,12 +76,13 @@ def lib(omp=False):
 
 
 def _dp(a):
-    return a.ctypes.data_as(C.POINTER(C.c_double))
+    return a.ctypes.data_as(C.POINTER(C.c_float if a.dtype == np.float32 else C.c_double))
 
 
-def default_config(**kw):
-    c = Config()
-    lib().piho_default_config(C.byref(c))
+def default_config(_lib=None, **kw):
+    L = _lib or lib()
+    c = L._cfg_type()
+    L.piho_default_config(C.byref(c))
     for k, v in kw.items():
         if not hasattr(c, k):
             raise AttributeError(k)
@@ -75,13 +93,14 @@ def default_config(**kw):
 class Oracle:
     """N-env fp64 CPU simulator with the same step/reset/get_state surface as the HIP product."""
 
-    def __init__(self, n_envs=1, offsets=None, omp=False, **kw):
-        self.L = lib(omp)
-        self.cfg = default_config(n_envs=n_envs, **kw)
+    def __init__(self, n_envs=1, offsets=None, omp=False, lib_path=None, **kw):
+        self.L = lib(omp, lib_path)
+        self.real = self.L._np_real           # float64 for the checker builds; float32 only for the fp32 CPU-baseline build
+        self.cfg = default_config(self.L, n_envs=n_envs, **kw)
         self.n = n_envs
         off = None
         if offsets is not None:
-            off = np.ascontiguousarray(offsets, dtype=np.float64).reshape(n_envs, 3)
+            off = np.ascontiguousarray(offsets, dtype=self.real).reshape(n_envs, 3)
         self.h = self.L.piho_create(C.byref(self.cfg), _dp(off) if off is not None else None)
 
     def __del__(self):
@@ -99,22 +118,22 @@ class Oracle:
         self.L.piho_reseed(self.h, int(seed))
 
     def step(self, actions):
-        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n, 4)
-        obs = np.zeros((self.n, 5)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.uint8)
+        a = np.ascontiguousarray(actions, dtype=self.real).reshape(self.n, 4)
+        obs = np.zeros((self.n, 5), self.real); rew = np.zeros(self.n, self.real); done = np.zeros(self.n, dtype=np.uint8)
         self.L.piho_step(self.h, _dp(a), _dp(obs), _dp(rew), done.ctypes.data_as(C.POINTER(C.c_uint8)))
         return obs, rew, done
 
     def get_state(self):
-        s = np.zeros((self.n, STATE_WORDS)); self.L.piho_get_state(self.h, _dp(s)); return s
+        s = np.zeros((self.n, STATE_WORDS), self.real); self.L.piho_get_state(self.h, _dp(s)); return s
 
     def set_state(self, s):
-        s = np.ascontiguousarray(s, dtype=np.float64).reshape(self.n, STATE_WORDS); self.L.piho_set_state(self.h, _dp(s))
+        s = np.ascontiguousarray(s, dtype=self.real).reshape(self.n, STATE_WORDS); self.L.piho_set_state(self.h, _dp(s))
 
     def tip_pose(self):
-        t = np.zeros((self.n, 7)); self.L.piho_get_tip_pose(self.h, _dp(t)); return t
+        t = np.zeros((self.n, 7), self.real); self.L.piho_get_tip_pose(self.h, _dp(t)); return t
 
     def contact_force(self):
-        f = np.zeros(self.n); self.L.piho_get_contact_force(self.h, _dp(f)); return f
+        f = np.zeros(self.n, self.real); self.L.piho_get_contact_force(self.h, _dp(f)); return f
 
     def ncontacts(self):
         n = np.zeros(self.n, dtype=np.int32); self.L.piho_get_ncontacts(self.h, n.ctypes.data_as(C.POINTER(C.c_int32))); return n

@@ -19,6 +19,12 @@
 extern "C" {
 #endif
 
+#ifndef PIHO_REAL
+#define PIHO_REAL double
+#endif
+typedef PIHO_REAL piho_real;   /* every array and scalar of this API; double for the checker builds */
+int piho_real_bytes(void);
+
 #define PIHO_STATE_WORDS 128
 #define PIHO_CMAX 48          /* max simultaneous contacts per env (same caps as the product) */
 #define PIHO_CAMAX 12         /* of which may involve the arm */
@@ -43,57 +49,57 @@ typedef struct {
   int32_t env_index0;         /* global index of env 0 (block partition across ranks): env seeds = seed + 1000 + global index */
   int32_t enable_arm_collision; /* 1: arm collision spheres (pih_model.h PIH_ARM_SPH_*) vs the table plane */
   uint64_t seed;
-  double dt;                  /* 1/240 */
-  double residual_threshold;  /* 1e-7 (squared velocity residual), 0 = never exit early */
-  double erp;                 /* 0.2 */
-  double warmstart;           /* 0.85 */
-  double contact_margin;      /* 0.005 */
-  double linear_slop;         /* 1e-5 */
-  double ik_damping;          /* 0.5 */
-  double ik_residual;         /* 1e-4 */
-  double dv;                  /* per-step EE clamp: 2/240 action mode (envs/utils.py:60), 0.05 scripted (envs/peg_in_hole.py:259) */
+  piho_real dt;                  /* 1/240 */
+  piho_real residual_threshold;  /* 1e-7 (squared velocity residual), 0 = never exit early */
+  piho_real erp;                 /* 0.2 */
+  piho_real warmstart;           /* 0.85 */
+  piho_real contact_margin;      /* 0.005 */
+  piho_real linear_slop;         /* 1e-5 */
+  piho_real ik_damping;          /* 0.5 */
+  piho_real ik_residual;         /* 1e-4 */
+  piho_real dv;                  /* per-step EE clamp: 2/240 action mode (envs/utils.py:60), 0.05 scripted (envs/peg_in_hole.py:259) */
 } piho_config;
 
 typedef struct piho_handle piho_handle;
 
 void piho_default_config(piho_config* c);
-piho_handle* piho_create(const piho_config* c, const double* offsets /* [n,3] or NULL */);
+piho_handle* piho_create(const piho_config* c, const piho_real* offsets /* [n,3] or NULL */);
 void piho_destroy(piho_handle* h);
 void piho_reset(piho_handle* h, const uint8_t* mask /* [n] or NULL = all */);
 void piho_reset_hard(piho_handle* h, const uint8_t* mask);   /* also forgets the RNG draw counter and the non-finite-reset count */
 void piho_reseed(piho_handle* h, uint64_t seed);
 /* actions [n,4]; obs [n,5]; reward [n]; done [n] */
-void piho_step(piho_handle* h, const double* actions, double* obs, double* reward, uint8_t* done);
-void piho_get_state(const piho_handle* h, double* out /* [n,128] */);
-void piho_set_state(piho_handle* h, const double* in /* [n,128] */);   /* also clears the warm-start cache */
-void piho_get_tip_pose(const piho_handle* h, double* out /* [n,7] */);
-void piho_get_contact_force(const piho_handle* h, double* out /* [n] sum of normal impulses / dt of the last step */);
+void piho_step(piho_handle* h, const piho_real* actions, piho_real* obs, piho_real* reward, uint8_t* done);
+void piho_get_state(const piho_handle* h, piho_real* out /* [n,128] */);
+void piho_set_state(piho_handle* h, const piho_real* in /* [n,128] */);   /* also clears the warm-start cache */
+void piho_get_tip_pose(const piho_handle* h, piho_real* out /* [n,7] */);
+void piho_get_contact_force(const piho_handle* h, piho_real* out /* [n] sum of normal impulses / dt of the last step */);
 void piho_get_ncontacts(const piho_handle* h, int32_t* out /* [n] */);
 
 /* PegInHole.render (envs/peg_in_hole.py:276-304) as an analytic ray caster: out [n,H,W,4] = depth, r, g, b */
-void piho_render(const piho_handle* h, int W, int H, double* out);
+void piho_render(const piho_handle* h, int W, int H, piho_real* out);
 /* grasp-rectangle label images of random_grasp (envs/peg_in_hole.py:72-99): out [4,S,S] = pos, sin, cos, wid; meta [5] */
-void piho_grasp_labels(double angle, int S, double* out, double* meta);
+void piho_grasp_labels(piho_real angle, int S, piho_real* out, piho_real* meta);
 
 /* stand-alone primitives (KATs and stage-wise GPU bring-up) */
-void piho_fk_arm(const double q[9], int link /* 0..8, or 9 = EE */, double pos[3], double quat[4]);
-void piho_jacobian_ee(const double q[9], double Jlin[27], double Jang[27]);     /* row-major 3x9 each */
-void piho_ik(const piho_config* c, const double q0[9], const double tpos[3], const double tquat[4], double qout[9]);
+void piho_fk_arm(const piho_real q[9], int link /* 0..8, or 9 = EE */, piho_real pos[3], piho_real quat[4]);
+void piho_jacobian_ee(const piho_real q[9], piho_real Jlin[27], piho_real Jang[27]);     /* row-major 3x9 each */
+void piho_ik(const piho_config* c, const piho_real q0[9], const piho_real tpos[3], const piho_real tquat[4], piho_real qout[9]);
 /* UR5 chain (envs/assets/urdf/ur5.urdf): getLinkState / Jacobian / calculateInverseKinematics for ur_execute (envs/utils.py:70-82) */
-void piho_fk_ur5(const double q[6], int link /* 0..5, or 6 = ee_link */, double pos[3], double quat[4]);
-void piho_jacobian_ur5(const double q[6], double Jlin[18], double Jang[18]);
-void piho_ik_ur5(const piho_config* c, const double q0[6], const double tpos[3], const double tquat[4], double qout[6]);
-void piho_mass_matrix(const double state[128], double M[38 * 38]);
-void piho_free_accel(const piho_config* c, const double state[128], double udot[38]);
-void piho_vel_constraint(const double cur[3], const double tar[3], double dv, double out[3]);
-void piho_rotate_vector(const double v[3], const double q[4], double out[3]);
-void piho_quat_from_euler(const double rpy[3], double q[4]);
-void piho_euler_from_quat(const double q[4], double rpy[3]);
-int piho_fsm_update(double* state, double* t, double dt);   /* envs/peg_in_hole.py:206-212 */
-void piho_env_offsets(const double offset[3], int n, double* out /* [n,3] */);   /* envs/base_env.py:35-55 */
+void piho_fk_ur5(const piho_real q[6], int link /* 0..5, or 6 = ee_link */, piho_real pos[3], piho_real quat[4]);
+void piho_jacobian_ur5(const piho_real q[6], piho_real Jlin[18], piho_real Jang[18]);
+void piho_ik_ur5(const piho_config* c, const piho_real q0[6], const piho_real tpos[3], const piho_real tquat[4], piho_real qout[6]);
+void piho_mass_matrix(const piho_real state[128], piho_real M[38 * 38]);
+void piho_free_accel(const piho_config* c, const piho_real state[128], piho_real udot[38]);
+void piho_vel_constraint(const piho_real cur[3], const piho_real tar[3], piho_real dv, piho_real out[3]);
+void piho_rotate_vector(const piho_real v[3], const piho_real q[4], piho_real out[3]);
+void piho_quat_from_euler(const piho_real rpy[3], piho_real q[4]);
+void piho_euler_from_quat(const piho_real q[4], piho_real rpy[3]);
+int piho_fsm_update(piho_real* state, piho_real* t, piho_real dt);   /* envs/peg_in_hole.py:206-212 */
+void piho_env_offsets(const piho_real offset[3], int n, piho_real* out /* [n,3] */);   /* envs/base_env.py:35-55 */
 /* debug: contact list + solver rows of env 0 from the last step */
-int piho_debug_contacts(const piho_handle* h, int env, double* out /* [CMAX,12]: linkA linkB px py pz nx ny nz depth mu key lambda_n */);
-void piho_debug_udot(const piho_handle* h, int env, double* out /* [38] free acceleration of the last step */);
+int piho_debug_contacts(const piho_handle* h, int env, piho_real* out /* [CMAX,12]: linkA linkB px py pz nx ny nz depth mu key lambda_n */);
+void piho_debug_udot(const piho_handle* h, int env, piho_real* out /* [38] free acceleration of the last step */);
 
 #ifdef __cplusplus
 }

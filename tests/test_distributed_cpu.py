@@ -48,3 +48,21 @@ def test_block_sharding_matches_single_process(oracle_mod):
     for t in range(steps):
         obs, _, _ = o.step(acts[t])
     np.testing.assert_allclose(gathered, obs, atol=1e-6)      # sharded + gathered == one big batch, env seeds by GLOBAL index
+
+
+def test_bench_gpus_flag_spawns_ranks_end_to_end():
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself (before touching a GPU), run the barrier +
+    all-gather + max-over-ranks timing path and have rank 0 print ONE JSON line with n_gpus = 2 (dry run: no env, gloo)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1",
+                          "--preroll", "2", "--total-envs", "16384"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong" and d["dry_run"] is True
+    assert d["config"]["envs_per_gpu"] == 8192 and d["config"]["total_envs"] == 16384 and "all-gather" in d["config"]["parallelism"]
+    for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+        assert k in d

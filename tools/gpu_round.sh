@@ -1,0 +1,28 @@
+#!/bin/bash
+# One GPU-box session: parity tests, driver-shaped and default bench lines, rocprofv3 kernel stats of the profiled bench.
+# usage (from the repo root on the box): bash tools/gpu_round.sh <tag> [tests|notests]
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+if [ "${2:-tests}" = "tests" ]; then
+  timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > $O/gpu_tests_$TAG.log 2>&1 || { echo "GPU TESTS FAILED"; tail -30 $O/gpu_tests_$TAG.log; exit 1; }
+  tail -3 $O/gpu_tests_$TAG.log
+fi
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_driver.json 2> $O/bench_${TAG}_driver.err || { echo "BENCH FAILED"; tail -20 $O/bench_${TAG}_driver.err; exit 1; }
+timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_${TAG}.json 2> $O/bench_${TAG}.err || { echo "BENCH FAILED"; tail -20 $O/bench_${TAG}.err; exit 1; }
+python - <<PY
+import json
+for f in ("bench_${TAG}_driver.json", "bench_${TAG}.json"):
+    d = json.loads(open("$O/" + f).read().strip().splitlines()[-1])
+    print(f, "%.3f M env-steps/s" % (d["value"] / 1e6), "kernel %.4f ms pre %.4f ms" % (d["roofline"]["kernel_avg_ms"], d["roofline"]["pre_kernel_avg_ms"]), "contacts", d["sanity"]["mean_contacts_start"], d["sanity"]["mean_contacts_end"], "cpu", d.get("cpu_baseline", {}).get("value"))
+PY
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/prof_$TAG
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/profiled_bench_$TAG.json 2> $O/profiled_bench_$TAG.err || { echo "PROFILED BENCH FAILED"; tail -20 $O/profiled_bench_$TAG.err; exit 1; }
+cd $R
+f=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1)
+head -8 "$f"
+cp "$f" $O/kernel_stats_$TAG.csv
+find $O/prof_$TAG -name "*kernel_trace.csv" -delete
