@@ -33,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_ENV_STEP = 828          # 98 state words R+W + action 16 + obs 20 + reward 4 + done 4
+ALG_BYTES_FLY = 400                   # SURVEY.md 8d (UR5 + random-fly): 43 state words R+W (344) + action 24 + obs 24 + reward 4 + done 4
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 
@@ -125,6 +126,47 @@ def cpu_baseline(preroll=300, budget_s=25.0):
             "rows": rows}
 
 
+def cpu_baseline_fly(preroll=300, budget_s=20.0):
+    """The same for the random-fly task (oracle/pih_fly_oracle.c): fp32 / fp64 all cores, and N = 1 on one thread."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    outdir = tempfile.mkdtemp(prefix="pih_oracle_native_")
+    p64, p32 = O.build_native(outdir)
+    rng = np.random.default_rng(1234)
+    rows = []
+
+    def run(path, n, pre, steps, label, threads):
+        o = O.FlyOracle(n, lib_path=path, auto_reset=1, dt=1.0 / 120.0)
+        acts = rng.uniform(-1, 1, (64, n, 6))
+        for t in range(pre):
+            o.step(acts[t % 64])
+        t0 = time.perf_counter()
+        for t in range(steps):
+            o.step(acts[(pre + t) % 64])
+        dt = time.perf_counter() - t0
+        rows.append({"label": label, "value": n * steps / dt, "unit": "env-steps/s", "envs": n, "steps": steps, "preroll": pre, "threads": threads})
+        return rows[-1]
+
+    probe = run(p32, 64 * cores, 0, 20, "probe", cores); rows.clear()
+    timed = 100
+    n = int(max(8 * cores, min(16384, (0.4 * budget_s * probe["value"]) / (preroll + timed))))
+    n -= n % cores
+    main = run(p32, n, preroll, timed, "fp32 -O3 -march=native, OpenMP over envs, %d threads" % cores, cores)
+    run(p64, n, preroll, timed, "fp64 -O3 -march=native, OpenMP over envs, %d threads" % cores, cores)
+    import ctypes
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+        run(p32, 1, 0, 1000, "fp32 -O3 -march=native, N = 1 env, 1 thread, 1000 steps from reset", 1)
+        run(p64, 1, 0, 1000, "fp64 -O3 -march=native, N = 1 env, 1 thread, 1000 steps from reset", 1)
+    finally:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    return {"value": main["value"], "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d steps after a %d-step pre-roll, fp32 build of the CPU restatement in oracle/pih_fly_oracle.c (NOT PyBullet), "
+                      "gcc -O3 -march=native, OpenMP over envs on all %d cores" % (n, timed, preroll, cores), "rows": rows}
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -150,6 +192,7 @@ def main():
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--task", default="peg-in-hole", choices=["peg-in-hole", "random-fly"], help="random-fly = BASELINE configs[4]: UR5 + free-flying object, args=['Banana', 1/120.]")
     ap.add_argument("--mode", default="action", choices=["action", "scripted"], help="action = panda_execute per step (headline); scripted = the reference's grasp-and-insert state machine")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (1-GPU box, gloo backend)")
@@ -195,23 +238,31 @@ def main():
             torch.cuda.synchronize(dev)
 
     env = None
+    fly = args.task == "random-fly"
+    adim, odim = (6, 6) if fly else (4, 5)
+    alg_bytes = ALG_BYTES_FLY if fly else ALG_BYTES_PER_ENV_STEP
     if use_gpu:
         from peg_in_hole_gym_amd.vec_env import PihVecEnv
-        mode_kw = dict(mode=1, dv=0.05) if args.mode == "scripted" else {}
-        env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, max_episode_steps=2227, seed=args.seed, **mode_kw)
+        if fly:
+            env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, seed=args.seed, task_id=1, dt=1.0 / 120.0, max_episode_steps=480, contact_margin=0.02)
+        else:
+            mode_kw = dict(mode=1, dv=0.05) if args.mode == "scripted" else {}
+            env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, max_episode_steps=2227, seed=args.seed, **mode_kw)
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         pool = min(args.steps + args.warmup + args.preroll, 1024)
-        actions = torch.rand(pool, n, 4, device=dev, generator=gen) * 2 - 1       # resident in HBM before the timed region
-    local_obs = torch.zeros(n, 5, device=dev)
-    gathered = torch.empty(world * n, 5, device=dev) if world > 1 and not args.no_allgather else None
+        actions = torch.rand(pool, n, adim, device=dev, generator=gen) * 2 - 1       # resident in HBM before the timed region
+    local_obs = torch.zeros(n, odim, device=dev)
+    gathered = torch.empty(world * n, odim, device=dev) if world > 1 and not args.no_allgather else None
 
     def one_step(t):
         obs = env.step(actions[t % pool])[0] if env is not None else local_obs
         if gathered is not None:
             dist.all_gather_into_tensor(gathered, obs)
 
+    cword, iword = (44, 32) if fly else (106, 107)
+
     def contacts():
-        return float(env.state()[:, 106].mean().item()) if env is not None else 0.0
+        return float(env.state()[:, cword].mean().item()) if env is not None else 0.0
 
     for t in range(args.preroll + args.warmup):
         one_step(t)
@@ -246,15 +297,15 @@ def main():
     if env is not None:
         st = env.state()
         finite = bool(torch.isfinite(st).all().item())
-        c_end = float(st[:, 106].mean().item())
-        mean_iters = float(st[:, 107].mean().item())
+        c_end = float(st[:, cword].mean().item())
+        mean_iters = float(st[:, iword].mean().item())
 
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed if not args.dry_run else None
-        achieved = ALG_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, traffic_detail = pmc_traffic(n)
-        fl = counted_flops()
+        achieved = alg_bytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic, traffic_detail = pmc_traffic(n) if not fly else (None, None)
+        fl = counted_flops() if not fly else None
         note = "latency/VALU/LDS-bound path (SURVEY.md 0.6): HBM fraction is ~0 by construction"
         if fl and kernel_ms > 0:
             tf = fl["flop_per_env_step"] * n / (kernel_ms * 1e-3) / 1e12
@@ -264,22 +315,24 @@ def main():
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Panda peg-in-hole, %d parallel envs per GPU, %s, dt=1/240, auto-reset, pre-rolled %d steps to contact steady state" % (
+            "config": {"workload": ("UR5 + random-fly (args=['Banana', 1/120.]), %d parallel envs per GPU, random actions U(-1,1)^6 through ur_execute, dt=1/120, auto-reset, pre-rolled %d steps" % (n, args.preroll)) if fly else
+                                   "Panda peg-in-hole, %d parallel envs per GPU, %s, dt=1/240, auto-reset, pre-rolled %d steps to contact steady state" % (
                            n, "random actions U(-1,1)" if args.mode == "action" else "scripted grasp-and-insert episodes", args.preroll),
+                       "task": args.task,
                        "envs_per_gpu": n, "total_envs": total_envs, "preroll": args.preroll,
                        "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + %s all-gather(obs)" % ("RCCL" if args.backend == "nccl" and use_gpu else "gloo"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (ALG_BYTES_PER_ENV_STEP * n),
-                         "kernel": "pih_step_kernel", "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches,
-                         "alg_bytes_per_env_step": ALG_BYTES_PER_ENV_STEP, "note": note},
+                         "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (alg_bytes * n),
+                         "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel", "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches,
+                         "alg_bytes_per_env_step": alg_bytes, "note": note},
             "sanity": {"state_finite": finite, "mean_contacts": 0.5 * (c_start + c_end), "mean_contacts_start": c_start, "mean_contacts_end": c_end,
-                       "mean_pgs_iters": mean_iters},
+                       ("mean_episode_step" if fly else "mean_pgs_iters"): mean_iters},
         }
         if args.dry_run:
             out["dry_run"] = True
         if not args.no_cpu_baseline and world == 1 and not args.dry_run:
             try:
-                out["cpu_baseline"] = cpu_baseline(preroll=args.preroll)
+                out["cpu_baseline"] = cpu_baseline_fly(preroll=args.preroll) if fly else cpu_baseline(preroll=args.preroll)
             except Exception as ex:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(out), flush=True)

@@ -52,9 +52,24 @@ enum {
   PIH_S_CACHE_N = 128, PIH_S_CACHE_KEY = 129, PIH_S_CACHE_LAMBDA = 129 + 48
 };
 
+/* ---- 'random-fly' task (PIH_TASK_RANDOM_FLY; README.md:38, ur_execute envs/utils.py:70-82, banana.urdf): record of
+ * PIH_FLY_STATE_WORDS float words per env.  Inside the library the fly state is structure-of-arrays [word][env] (one env per
+ * lane, coalesced loads); pih_get_state / pih_set_state(PIH_FIELD_STATE) exchange it env-major, float[n, PIH_FLY_STATE_WORDS]. */
+#define PIH_FLY_STATE_WORDS 48
+#define PIH_FLY_ACTION_DIM 6   /* ee target xyz (world) + euler rpy, envs/utils.py:71-72 */
+#define PIH_FLY_OBS_DIM 6      /* ee xyz + object xyz (world); build-defined, SURVEY.md 8d */
+enum {
+  PIH_F_Q = 0, PIH_F_QD = 6, PIH_F_TARGET = 12,                       /* UR5 joints 1..6 (envs/utils.py:46,82), their rates, IK targets */
+  PIH_F_OPOS = 18, PIH_F_OQUAT = 21, PIH_F_OVLIN = 25, PIH_F_OVANG = 28,   /* object pose (env-local) and twist */
+  PIH_F_DONE = 31, PIH_F_STEPS = 32, PIH_F_RNG = 33, PIH_F_RNG_HI = 34, PIH_F_OFFSET = 35, PIH_F_SPARE = 38, PIH_F_INVALID = 39,
+  PIH_F_EE = 40,          /* world position of ee_link after the last step / reset (3) */
+  PIH_F_CFORCE = 43,      /* sum of contact normal impulses / dt of the last step [N] */
+  PIH_F_NCONTACT = 44
+};
+
 /* pih_get_state / pih_set_state fields */
 enum {
-  PIH_FIELD_STATE = 0,         /* float[n, PIH_STATE_WORDS] */
+  PIH_FIELD_STATE = 0,         /* float[n, PIH_STATE_WORDS] (random-fly: float[n, PIH_FLY_STATE_WORDS]) */
   PIH_FIELD_TIP_POSE = 1,      /* float[n, 7]  (get only)  envs/peg_in_hole.py:58,115 */
   PIH_FIELD_CONTACT_FORCE = 2, /* float[n]     (get only)  north_star contact-normal force */
   PIH_FIELD_DEBUG = 3,         /* float[n, PIH_DEBUG_WORDS] (get only; filled when config.debug != 0) */
@@ -97,6 +112,8 @@ typedef struct pih_handle pih_handle;
 
 void pih_default_config(pih_config* cfg);
 int pih_abi_version(void);
+/* per-task sizes of the tensors the caller owns: out[0] = action dim, out[1] = obs dim, out[2] = state words per env */
+int pih_task_dims(int task_id, int32_t out[3]);
 /* offsets_host: HOST float[n_envs,3] (envs/base_env.py:35-55 placement) or NULL for zeros */
 int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** out);
 int pih_destroy(pih_handle* h);
@@ -106,7 +123,8 @@ int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, void* stream);
 /* new base seed for all later resets (env seed = seed + 1000 + global env index); combine with a hard reset to restart the
  * draw sequence.  The reference never seeds (envs/peg_in_hole.py:239-267 use the global `random`). */
 int pih_reseed(pih_handle* h, uint64_t seed);
-/* actions_dev float[n,4]; obs_dev float[n,5]; reward_dev float[n]; done_dev uint8[n] */
+/* actions_dev float[n,4]; obs_dev float[n,5]; reward_dev float[n]; done_dev uint8[n]
+ * (PIH_TASK_RANDOM_FLY: actions float[n,6], obs float[n,6]) */
 int pih_step(pih_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 /* k consecutive steps with the same action buffer (scripted mode ignores actions: may be NULL) in one call */
 int pih_step_n(pih_handle* h, int k, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);

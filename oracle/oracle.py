@@ -230,3 +230,83 @@ def fsm_trace(n_steps, dt=1.0 / 240):
 def env_offsets(offset, n):
     o = np.ascontiguousarray(offset, dtype=np.float64); out = np.zeros((n, 3))
     lib().piho_env_offsets(_dp(o), C.c_int(n), _dp(out)); return out
+
+
+# ---- 'random-fly' task (UR5 + free-flying object), oracle/pih_fly_oracle.c
+FLY_STATE_WORDS = 48
+F_Q, F_QD, F_TARGET, F_OPOS, F_OQUAT, F_OVLIN, F_OVANG, F_DONE, F_STEPS, F_RNG, F_RNG_HI, F_OFFSET, F_SPARE, F_INVALID, F_EE, F_CFORCE, F_NCONTACT = \
+    0, 6, 12, 18, 21, 25, 28, 31, 32, 33, 34, 35, 38, 39, 40, 43, 44
+
+
+def _fly_protos(L):
+    if getattr(L, "_fly_ready", False):
+        return L
+    dp = C.POINTER(C.c_float if L._np_real is np.float32 else C.c_double)
+    L.piho_fly_create.restype = C.c_void_p
+    L.piho_fly_create.argtypes = [C.POINTER(L._cfg_type), dp]
+    L.piho_fly_destroy.argtypes = [C.c_void_p]
+    L.piho_fly_reset.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
+    L.piho_fly_step.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_uint8)]
+    L.piho_fly_get_state.argtypes = [C.c_void_p, dp]
+    L.piho_fly_set_state.argtypes = [C.c_void_p, dp]
+    L.piho_fly_debug_contacts.argtypes = [C.c_void_p, C.c_int, dp]
+    L.piho_fly_debug_udot.argtypes = [C.c_void_p, C.c_int, dp]
+    L.piho_fly_mass_matrix.argtypes = [dp, dp]
+    L.piho_fly_arm_kinetic_energy.argtypes = [dp, dp]
+    L.piho_fly_arm_kinetic_energy.restype = C.c_float if L._np_real is np.float32 else C.c_double
+    L.piho_fly_random_pos.argtypes = [C.c_uint64, C.c_uint64, dp]
+    L._fly_ready = True
+    return L
+
+
+class FlyOracle:
+    """N-env CPU simulator of the random-fly task with the same step/reset/get_state surface as the HIP product (task_id 1)."""
+
+    def __init__(self, n_envs=1, offsets=None, omp=False, lib_path=None, **kw):
+        self.L = _fly_protos(lib(omp, lib_path))
+        self.real = self.L._np_real
+        kw.setdefault("max_episode_steps", 480)
+        kw.setdefault("contact_margin", 0.02)      # Bullet's contact breaking threshold: the object moves centimetres per step
+        self.cfg = default_config(self.L, n_envs=n_envs, **kw)
+        self.n = n_envs
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=self.real).reshape(n_envs, 3)
+        self.h = self.L.piho_fly_create(C.byref(self.cfg), _dp(off) if off is not None else None)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.piho_fly_destroy(self.h); self.h = None
+
+    def reset(self, mask=None, hard_reset=False):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self.L.piho_fly_reset(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None, int(hard_reset))
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=self.real).reshape(self.n, 6)
+        obs = np.zeros((self.n, 6), self.real); rew = np.zeros(self.n, self.real); done = np.zeros(self.n, dtype=np.uint8)
+        self.L.piho_fly_step(self.h, _dp(a), _dp(obs), _dp(rew), done.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return obs, rew, done
+
+    def get_state(self):
+        s = np.zeros((self.n, FLY_STATE_WORDS), self.real); self.L.piho_fly_get_state(self.h, _dp(s)); return s
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, dtype=self.real).reshape(self.n, FLY_STATE_WORDS); self.L.piho_fly_set_state(self.h, _dp(s))
+
+    def debug_contacts(self, env=0):
+        out = np.zeros((10, 10), self.real); self.L.piho_fly_debug_contacts(self.h, env, _dp(out)); return out
+
+    def debug_udot(self, env=0):
+        out = np.zeros(12, self.real); self.L.piho_fly_debug_udot(self.h, env, _dp(out)); return out
+
+
+def fly_mass_matrix(q):
+    L = _fly_protos(lib()); q = np.ascontiguousarray(q, dtype=np.float64); M = np.zeros((6, 6)); L.piho_fly_mass_matrix(_dp(q), _dp(M)); return M
+
+
+def fly_arm_kinetic_energy(q, qd):
+    L = _fly_protos(lib()); q = np.ascontiguousarray(q, dtype=np.float64); qd = np.ascontiguousarray(qd, dtype=np.float64)
+    return L.piho_fly_arm_kinetic_energy(_dp(q), _dp(qd))
+
+
+def fly_random_pos(seed, ctr=0):
+    L = _fly_protos(lib()); out = np.zeros(3); L.piho_fly_random_pos(int(seed), int(ctr), _dp(out)); return out

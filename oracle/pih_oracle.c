@@ -1112,3 +1112,5 @@ void piho_free_accel(const piho_config* c, const real state[128], real udot[38])
   minv_apply(M, udot);
 }
 int piho_real_bytes(void) { return (int)sizeof(real); }
+
+#include "pih_fly_oracle.c"   /* the 'random-fly' task (UR5 + free-flying object); shares the static helpers above */

@@ -101,6 +101,31 @@ void piho_env_offsets(const piho_real offset[3], int n, piho_real* out /* [n,3] 
 int piho_debug_contacts(const piho_handle* h, int env, piho_real* out /* [CMAX,12]: linkA linkB px py pz nx ny nz depth mu key lambda_n */);
 void piho_debug_udot(const piho_handle* h, int env, piho_real* out /* [38] free acceleration of the last step */);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * 'random-fly' task (BASELINE.json configs[4]; README.md:38): UR5 (ur_execute, envs/utils.py:70-82) + one free-flying object
+ * (banana.urdf) spawned by random_pos_in_panda_space (envs/utils.py:97-107).  See pih_fly_oracle.c. */
+#define PIHO_FLY_STATE_WORDS 48
+#define PIHO_FLY_ACTION_DIM 6   /* ee target xyz + euler rpy (envs/utils.py:71-72) */
+#define PIHO_FLY_OBS_DIM 6      /* ee xyz + object xyz (build-defined) */
+enum {   /* identical to the product's record (include/pih.h PIH_F_*) */
+  PIHO_F_Q = 0, PIHO_F_QD = 6, PIHO_F_TARGET = 12, PIHO_F_OPOS = 18, PIHO_F_OQUAT = 21, PIHO_F_OVLIN = 25, PIHO_F_OVANG = 28,
+  PIHO_F_DONE = 31, PIHO_F_STEPS = 32, PIHO_F_RNG = 33, PIHO_F_RNG_HI = 34, PIHO_F_OFFSET = 35, PIHO_F_SPARE = 38, PIHO_F_INVALID = 39,
+  PIHO_F_EE = 40, PIHO_F_CFORCE = 43, PIHO_F_NCONTACT = 44
+};
+typedef struct piho_fly_handle piho_fly_handle;
+piho_fly_handle* piho_fly_create(const piho_config* c, const piho_real* offsets /* [n,3] or NULL */);
+void piho_fly_destroy(piho_fly_handle* h);
+void piho_fly_reset(piho_fly_handle* h, const uint8_t* mask, int hard);
+/* actions [n,6]; obs [n,6]; reward [n]; done [n] */
+void piho_fly_step(piho_fly_handle* h, const piho_real* actions, piho_real* obs, piho_real* reward, uint8_t* done);
+void piho_fly_get_state(const piho_fly_handle* h, piho_real* out /* [n,48] */);
+void piho_fly_set_state(piho_fly_handle* h, const piho_real* in);
+void piho_fly_debug_contacts(const piho_fly_handle* h, int env, piho_real* out /* [10,10]: valid link p n depth lambda_n per slot */);
+void piho_fly_debug_udot(const piho_fly_handle* h, int env, piho_real* out /* [12] */);
+void piho_fly_mass_matrix(const piho_real q[6], piho_real M[36]);
+piho_real piho_fly_arm_kinetic_energy(const piho_real q[6], const piho_real qd[6]);
+void piho_fly_random_pos(uint64_t seed, uint64_t ctr, piho_real out[3]);   /* envs/utils.py:97-107 with the counter RNG */
+
 #ifdef __cplusplus
 }
 #endif

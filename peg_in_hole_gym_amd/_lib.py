@@ -18,7 +18,7 @@ S_SPARE, S_TIP, S_CFORCE, S_NCONTACT, S_PGS_ITERS, S_INVALID, S_CACHE_N = 97, 98
 TASK_PEG_IN_HOLE, TASK_RANDOM_FLY = 0, 1
 ABI_VERSION = 3
 
-EXPORTS = ["pih_default_config", "pih_abi_version", "pih_create", "pih_destroy", "pih_reset", "pih_reseed", "pih_step", "pih_step_n",
+EXPORTS = ["pih_default_config", "pih_abi_version", "pih_task_dims", "pih_create", "pih_destroy", "pih_reset", "pih_reseed", "pih_step", "pih_step_n",
            "pih_get_state", "pih_set_state", "pih_ik", "pih_ik_ur5", "pih_render", "pih_grasp_labels", "pih_timing", "pih_timing2", "pih_set_timing", "pih_last_error"]
 
 
@@ -55,6 +55,7 @@ def load():
     L.pih_default_config.argtypes = [C.POINTER(PihConfig)]
     L.pih_default_config.restype = None
     L.pih_abi_version.restype = C.c_int
+    L.pih_task_dims.argtypes = [C.c_int, C.POINTER(C.c_int32 * 3)]
     L.pih_create.argtypes = [C.POINTER(PihConfig), vp, C.POINTER(vp)]
     L.pih_destroy.argtypes = [vp]
     L.pih_reset.argtypes = [vp, vp, C.c_int, vp]
@@ -76,6 +77,20 @@ def load():
         raise PihError("%s has ABI version %d, this package expects %d: rebuild it" % (LIB_PATH, L.pih_abi_version(), ABI_VERSION))
     _lib = L
     return L
+
+
+FLY_STATE_WORDS, FLY_ACTION_DIM, FLY_OBS_DIM = 48, 6, 6
+# random-fly record word offsets (include/pih.h PIH_F_*)
+F_Q, F_QD, F_TARGET, F_OPOS, F_OQUAT, F_OVLIN, F_OVANG, F_DONE, F_STEPS, F_RNG, F_RNG_HI, F_OFFSET, F_SPARE, F_INVALID, F_EE, F_CFORCE, F_NCONTACT = \
+    0, 6, 12, 18, 21, 25, 28, 31, 32, 33, 34, 35, 38, 39, 40, 43, 44
+
+
+def task_dims(task_id):
+    """(action dim, obs dim, state words per env) of a task, from the library"""
+    out = (C.c_int32 * 3)()
+    if load().pih_task_dims(int(task_id), C.byref(out)) != 0:
+        raise PihError("unknown task_id %r" % (task_id,))
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def default_config(**kw):

@@ -1,0 +1,415 @@
+// pih_fly.h -- the 'random-fly' task (BASELINE.json configs[4]; README.md:38): UR5 + one free-flying object, ONE ENV PER LANE.
+//
+// What replaces what (paths relative to /root/reference/peg_in_hole_gym/):
+//   controller        ur_execute: getQuaternionFromEuler + calculateInverseKinematics + setJointMotorControlArray(POSITION_CONTROL,
+//                     positionGains 0.03, forces = URDF effort)                                   envs/utils.py:70-82
+//   reset_state       init_ur / reset_ur + random_pos_in_panda_space                              envs/utils.py:40-48,55-57,97-107
+//   step_env          p.stepSimulation for the UR5 (ur5.urdf) and the object (banana.urdf)        envs/base_env.py:64
+// The task CLASS is not in the reference snapshot (TASK_LIST holds only 'peg-in-hole', envs/base_env.py:9-11): rest pose, launch
+// law, reward / done and the observation are BUILD-DEFINED (same definitions as oracle/pih_fly_oracle.c).
+//
+// Mapping: the system is 12 DOF (6 arm joints + a free rigid body) with at most 10 frictionless contacts -- far too little
+// parallel work for a wavefront per env -- and its dominant cost is the 20 strictly sequential 6x6 DLS solves of the IK.  So
+// one env is one LANE: 64 envs per wavefront, plain scalar code per lane, state in HBM as structure-of-arrays
+// [word][env] so that every load / store of a wave is one coalesced 256 B segment.  The rigid-body quantities of the six links
+// stay in registers; the per-contact solver rows (Jacobian, response, right-hand side) are staged in LDS, lane-major
+// ([word][lane]: conflict-free, and a lane may index its rows dynamically without spilling to scratch).
+// Dynamics: articulated-body algorithm, world-aligned axes, link origin as reference point (as in pih_device.h), impulse
+// responses from the same articulated inertias; sequential-impulse PGS over (motor, lower limit, upper limit) per joint, then
+// the contact normals.  The oracle derives the same physics by RNEA + dense Cholesky.
+#pragma once
+#include "pih_device.h"
+
+namespace pih {
+namespace fly {
+
+constexpr int NJ = 6, FND = 12, NS = PIH_FLY_OBJ_NSPH, NC = 2 * NS;
+constexpr int SW = PIH_FLY_STATE_WORDS;
+constexpr int CW = 24;             // words of one contact row record in lane memory
+constexpr int LANE_WORDS = NC * CW;
+
+PIH_CONST real U_MASS[NJ] = PIH_UR5_MASS;
+PIH_CONST real U_COM[NJ][3] = PIH_UR5_COM;
+PIH_CONST real U_INERTIA[NJ][6] = PIH_UR5_INERTIA;
+PIH_CONST real U_DAMPING[NJ] = PIH_UR5_DAMPING;
+PIH_CONST real U_LO[NJ] = PIH_UR5_LO;
+PIH_CONST real U_HI[NJ] = PIH_UR5_HI;
+PIH_CONST real U_EFFORT[NJ] = PIH_UR5_EFFORT;
+PIH_CONST real U_CAP_A[NJ][3] = PIH_UR5_CAP_A;
+PIH_CONST real U_CAP_B[NJ][3] = PIH_UR5_CAP_B;
+PIH_CONST real U_CAP_R[NJ] = PIH_UR5_CAP_R;
+PIH_CONST real U_REST[NJ] = PIH_UR5_REST;
+PIH_CONST real O_INERTIA[3] = PIH_FLY_OBJ_INERTIA;
+PIH_CONST real O_SPH_C[NS][3] = PIH_FLY_OBJ_SPH_C;
+PIH_CONST real O_SPH_R[NS] = PIH_FLY_OBJ_SPH_R;
+
+// per-lane scratch: word w of this lane lives at p[w * stride] (GPU: LDS, stride 64; host emulation: a plain array, stride 1)
+struct LaneMem {
+  real* p; int stride;
+  PIH_HD real& at(int w) const { return p[w * stride]; }
+};
+
+// envs/utils.py:97-107 with the counter RNG (draws: x, the sqrt argument, the 0..0.4 offset, the sign; repeated while the point
+// falls outside the sphere)
+PIH_HD V3 random_pos_in_panda_space(uint64_t seed, uint64_t& ctr) {
+  const real U = (real)(1.0 / 16777216.0), len = (real)0.7;
+  real x = 1, y = 1;
+  while (len * len - x * x - y * y < 0) {
+    x = -len + 2 * len * ((real)rng24(seed, ctr++) * U);
+    const real a = (len * len - x * x) * ((real)rng24(seed, ctr++) * U);
+    const real b = (real)0.4 * ((real)rng24(seed, ctr++) * U);
+    const real sg = (rng24(seed, ctr++) >> 23) ? (real)1 : (real)-1;
+    y = ((real)sqrt(a) - b) * sg;
+  }
+  return mk(x, y, (real)sqrt(len * len - x * x - y * y) + (real)0.2);
+}
+
+// end-effector position of the UR5 chain (getLinkState(ur, ee)[0], envs/utils.py:80)
+PIH_HD V3 ee_position(const real* q) { V3 p; M3 R; chain_ee<Ur5Chain>(q, p, R); return p; }
+
+PIH_HD void reset_state(real* S, const Params& P, int env_global) {
+  const real off0 = S[PIH_F_OFFSET], off1 = S[PIH_F_OFFSET + 1], off2 = S[PIH_F_OFFSET + 2], nbad = S[PIH_F_SPARE];
+  uint64_t ctr = ((uint64_t)S[PIH_F_RNG_HI] << 24) + (uint64_t)S[PIH_F_RNG];
+  const uint64_t seed = P.seed + 1000ULL + (uint64_t)env_global;
+#pragma unroll
+  for (int i = 0; i < SW; i++) S[i] = 0;
+  S[PIH_F_OFFSET] = off0; S[PIH_F_OFFSET + 1] = off1; S[PIH_F_OFFSET + 2] = off2; S[PIH_F_SPARE] = nbad;
+#pragma unroll
+  for (int i = 0; i < NJ; i++) { S[PIH_F_Q + i] = U_REST[i]; S[PIH_F_TARGET + i] = U_REST[i]; }
+  const real U = (real)(1.0 / 16777216.0);
+  const V3 p0 = random_pos_in_panda_space(seed, ctr);
+  // BUILD-DEFINED launch law: aim at a point in front of the arm, flight time T, ballistic initial velocity, random spin
+  V3 c;
+  c.x = (real)-0.15 + (real)0.3 * ((real)rng24(seed, ctr++) * U); c.y = (real)-0.15 + (real)0.3 * ((real)rng24(seed, ctr++) * U);
+  c.z = (real)0.35 + (real)0.3 * ((real)rng24(seed, ctr++) * U);
+  const real T = (real)0.6 + (real)0.4 * ((real)rng24(seed, ctr++) * U);
+  V3 w0;
+  w0.x = (real)-3 + (real)6 * ((real)rng24(seed, ctr++) * U); w0.y = (real)-3 + (real)6 * ((real)rng24(seed, ctr++) * U);
+  w0.z = (real)-3 + (real)6 * ((real)rng24(seed, ctr++) * U);
+  const V3 v0 = ((real)1 / T) * (c - p0);
+  S[PIH_F_OPOS] = p0.x; S[PIH_F_OPOS + 1] = p0.y; S[PIH_F_OPOS + 2] = p0.z;
+  S[PIH_F_OVLIN] = v0.x; S[PIH_F_OVLIN + 1] = v0.y; S[PIH_F_OVLIN + 2] = v0.z - (real)0.5 * (real)PIH_GRAVITY_Z * T;
+  S[PIH_F_OVANG] = w0.x; S[PIH_F_OVANG + 1] = w0.y; S[PIH_F_OVANG + 2] = w0.z;
+  S[PIH_F_OQUAT + 3] = 1;
+  S[PIH_F_RNG] = (real)(ctr & 0xFFFFFFull); S[PIH_F_RNG_HI] = (real)((ctr >> 24) & 0xFFFFFFull);
+  const V3 ee = ee_position(S + PIH_F_Q);
+  S[PIH_F_EE] = ee.x + off0; S[PIH_F_EE + 1] = ee.y + off1; S[PIH_F_EE + 2] = ee.z + off2;
+}
+
+// symmetric 3x3 helpers
+PIH_HD S3 s3_add(const S3& a, const S3& b) { S3 r; r.xx = a.xx + b.xx; r.yy = a.yy + b.yy; r.zz = a.zz + b.zz; r.xy = a.xy + b.xy; r.xz = a.xz + b.xz; r.yz = a.yz + b.yz; return r; }
+PIH_HD S3 s3_diag(real d) { S3 r; r.xx = r.yy = r.zz = d; r.xy = r.xz = r.yz = 0; return r; }
+PIH_HD M3 m_add(const M3& a, const M3& b) { M3 r; for (int i = 0; i < 9; i++) r.m[i] = a.m[i] + b.m[i]; return r; }
+PIH_HD M3 m_transpose(const M3& a) { M3 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[3 * i + j] = a.m[3 * j + i]; return r; }
+PIH_HD M3 skew(V3 r) { M3 o; o.m[0] = 0; o.m[1] = -r.z; o.m[2] = r.y; o.m[3] = r.z; o.m[4] = 0; o.m[5] = -r.x; o.m[6] = -r.y; o.m[7] = r.x; o.m[8] = 0; return o; }
+// symmetric part of a (numerically almost symmetric) general 3x3
+PIH_HD S3 sym_of(const M3& a) { S3 r; r.xx = a.m[0]; r.yy = a.m[4]; r.zz = a.m[8]; r.xy = (real)0.5 * (a.m[1] + a.m[3]); r.xz = (real)0.5 * (a.m[2] + a.m[6]); r.yz = (real)0.5 * (a.m[5] + a.m[7]); return r; }
+
+// spatial inertia about a reference point: [[A, B], [B^T, C]] acting on (angular; linear) motion vectors
+struct SI { S3 A; M3 B; S3 C; };
+
+// One dt of one env.  S: the env's state record (a per-lane local array); mem: this lane's contact-row scratch.
+template <class Mem>
+PIH_HD void step_env(real* S, const Params& P, int env_global, const real* action, real* obs, real* reward, unsigned char* done, Mem mem, real* dbg) {
+  const real dt = P.dt;
+  const bool frozen = !P.autoreset && S[PIH_F_DONE] != 0;   // finished envs keep their last values (envs/base_env.py:62,66)
+  bool landed = false;
+  if (!frozen) {
+    // ---- controller: ur_execute (envs/utils.py:70-82)
+    real q[NJ], qd[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; i++) { q[i] = S[PIH_F_Q + i]; qd[i] = S[PIH_F_QD + i]; }
+    real vt[NJ];
+    {
+      Serial sw; real ikT[NJ][12]; real qs[NJ];
+      const Q4 tq = quat_from_euler(action[3], action[4], action[5]);
+      const V3 tp = mk(action[0] - S[PIH_F_OFFSET], action[1] - S[PIH_F_OFFSET + 1], action[2] - S[PIH_F_OFFSET + 2]);
+      ik_chain<Ur5Chain>(sw, ikT, P, q, tp, tq, qs);
+#pragma unroll
+      for (int i = 0; i < NJ; i++) { S[PIH_F_TARGET + i] = qs[i]; vt[i] = (real)PIH_UR5_KP * (qs[i] - q[i]) / dt; }
+    }
+    // ---- forward kinematics + per-link spatial inertia / bias force about the link origin, world axes
+    V3 o[NJ], a[NJ], r[NJ], wv[NJ], ca[NJ], cl[NJ];
+    SI I[NJ]; V3 pa[NJ], pl[NJ];        // articulated inertia / bias force (initialised with the link's own)
+    // object pose
+    Q4 oq; oq.x = S[PIH_F_OQUAT]; oq.y = S[PIH_F_OQUAT + 1]; oq.z = S[PIH_F_OQUAT + 2]; oq.w = S[PIH_F_OQUAT + 3];
+    const M3 Ro = q_to_m(oq);
+    const V3 op = ld3(S + PIH_F_OPOS);
+    V3 sc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) sc[i] = op + mul(Ro, ld3(O_SPH_C[i]));
+    // contact candidates of slot i (sphere i vs its deepest capsule): depth, link, normal, point
+    real cdepth[NS]; int clink[NS]; V3 cn[NS], cp[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) { cdepth[i] = PIH_BIG; clink[i] = -1; cn[i] = mk(0, 0, 1); cp[i] = mk(0, 0, 0); }
+    {
+      M3 Rp = ldm(IDENT3); V3 org = ld3(UR5_BASE_T), wp = mk(0, 0, 0), vp = mk(0, 0, 0), opar = org;
+#pragma unroll
+      for (int L = 0; L < NJ; L++) {
+        const M3 Rj = mul(Rp, ldm(UR5_RFIX[L]));
+        org = org + mul(Rp, ld3(UR5_TFIX[L]));
+        const M3 R = mul(Rj, axis_angle(ld3(UR5_AXIS[L]), q[L]));
+        o[L] = org; a[L] = mul(Rj, ld3(UR5_AXIS[L]));
+        r[L] = L == 0 ? mk(0, 0, 0) : org - opar;
+        // velocities: the joint axis passes through the link origin
+        const V3 aq = qd[L] * a[L];
+        const V3 vv = L == 0 ? mk(0, 0, 0) : vp + cross(wp, r[L]);
+        wv[L] = wp + aq;
+        ca[L] = cross(wp, aq); cl[L] = L == 0 ? mk(0, 0, 0) : cross(wp, cross(wp, r[L]));
+        // own spatial inertia about the origin and bias force (velocity products - gravity + Bullet link damping)
+        const real m = U_MASS[L];
+        const V3 rc = mul(R, ld3(U_COM[L]));
+        const S3 Ic = rot_sym(R, lds3(U_INERTIA[L]));
+        const real r2 = dot(rc, rc);
+        S3 A = Ic; A.xx += m * (r2 - rc.x * rc.x); A.yy += m * (r2 - rc.y * rc.y); A.zz += m * (r2 - rc.z * rc.z);
+        A.xy -= m * rc.x * rc.y; A.xz -= m * rc.x * rc.z; A.yz -= m * rc.y * rc.z;
+        I[L].A = A; I[L].B = skew(m * rc); I[L].C = s3_diag(m);
+        const V3 wrc = cross(wv[L], rc), vc = vv + wrc, Iw = mul(Ic, wv[L]);
+        const real sv = PIH_LIN_DAMP + PIH_LIN_DAMP * norm(vc), sw2 = PIH_ANG_DAMP + PIH_ANG_DAMP * norm(wv[L]);
+        const V3 f = m * cross(wv[L], wrc) - mk(0, 0, m * (real)PIH_GRAVITY_Z) + (m * sv) * vc;
+        pl[L] = f; pa[L] = cross(wv[L], Iw) + sw2 * Iw + cross(rc, f);
+        // collision: every object sphere against this link's capsule; keep the deepest per sphere (ties: lowest link)
+        const V3 A0 = org + mul(R, ld3(U_CAP_A[L])), B0 = org + mul(R, ld3(U_CAP_B[L]));
+        const V3 ab = B0 - A0; const real l2 = dot(ab, ab);
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+          const V3 ac = sc[i] - A0;
+          const real t = l2 > (real)1e-18 ? clampr(dot(ac, ab) / l2, 0, 1) : (real)0;
+          const V3 d = sc[i] - (A0 + t * ab);
+          const real dist = norm(d), depth = dist - O_SPH_R[i] - U_CAP_R[L];
+          if (depth < P.margin && depth < cdepth[i] && dist > (real)1e-9) {
+            cdepth[i] = depth; clink[i] = L; cn[i] = ((real)1 / dist) * d; cp[i] = sc[i] - (O_SPH_R[i] + (real)0.5 * depth) * cn[i];
+          }
+        }
+        Rp = R; wp = wv[L]; vp = vv; opar = org;
+      }
+    }
+    // ---- ABA inward sweep: U = I^A S, D, u; hand (I^a, p^a) up to the parent's origin
+    V3 Ua[NJ], Ul[NJ]; real Dinv[NJ], uu[NJ];
+#pragma unroll
+    for (int L = NJ - 1; L >= 0; L--) {
+      Ua[L] = mul(I[L].A, a[L]); Ul[L] = tmul(I[L].B, a[L]);           // S = [a; 0]: U = [A a; B^T a]
+      const real D = dot(a[L], Ua[L]);
+      Dinv[L] = (real)1 / D;
+      uu[L] = -U_DAMPING[L] * qd[L] - dot(a[L], pa[L]);
+      if (L > 0) {
+        // I^a = I^A - U U^T / D ; p^a = p^A + I^a c + U u / D
+        S3 Aa = I[L].A; sub_outer(Aa, Ua[L], Dinv[L]);
+        S3 Ca = I[L].C; sub_outer(Ca, Ul[L], Dinv[L]);
+        M3 Ba = I[L].B;
+        { const real ua[3] = {Ua[L].x, Ua[L].y, Ua[L].z}, ul[3] = {Ul[L].x, Ul[L].y, Ul[L].z};
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Ba.m[3 * i + j] -= ua[i] * ul[j] * Dinv[L]; }
+        const real ud = uu[L] * Dinv[L];
+        const V3 paa = pa[L] + mul(Aa, ca[L]) + mul(Ba, cl[L]) + ud * Ua[L];
+        const V3 pla = pl[L] + tmul(Ba, ca[L]) + mul(Ca, cl[L]) + ud * Ul[L];
+        // translate by r = o_L - o_parent: B' = B + [r]x C ; A' = A + [r]x B^T - B' [r]x ; p_a' = p_a + r x p_l
+        const M3 rx = skew(r[L]);
+        const M3 Bp = m_add(Ba, mul(rx, s3_to_m(Ca)));
+        const M3 Ap = m_add(m_add(s3_to_m(Aa), mul(rx, m_transpose(Ba))), mul_skew(Bp, -r[L]));
+        I[L - 1].A = s3_add(I[L - 1].A, sym_of(Ap)); I[L - 1].B = m_add(I[L - 1].B, Bp); I[L - 1].C = s3_add(I[L - 1].C, Ca);
+        pa[L - 1] = pa[L - 1] + paa + cross(r[L], pla); pl[L - 1] = pl[L - 1] + pla;
+      }
+    }
+    // ---- outward sweep: free accelerations
+    real udot[FND];
+    {
+      V3 alp = mk(0, 0, 0), acp = mk(0, 0, 0);
+#pragma unroll
+      for (int L = 0; L < NJ; L++) {
+        const V3 aa = alp + ca[L], ll = acp + cross(alp, r[L]) + cl[L];
+        const real qdd = (uu[L] - dot(Ua[L], aa) - dot(Ul[L], ll)) * Dinv[L];
+        udot[L] = qdd; alp = aa + qdd * a[L]; acp = ll;
+      }
+    }
+    // object: m a = m g - damping ; I alpha = -w x I w - damping (world axes)
+    const V3 ov = ld3(S + PIH_F_OVLIN), ow = ld3(S + PIH_F_OVANG);
+    S3 Iow, Ioi;
+    { S3 d; d.xx = O_INERTIA[0]; d.yy = O_INERTIA[1]; d.zz = O_INERTIA[2]; d.xy = d.xz = d.yz = 0; Iow = rot_sym(Ro, d);
+      S3 e; e.xx = (real)1 / O_INERTIA[0]; e.yy = (real)1 / O_INERTIA[1]; e.zz = (real)1 / O_INERTIA[2]; e.xy = e.xz = e.yz = 0; Ioi = rot_sym(Ro, e); }
+    {
+      const real sv = PIH_LIN_DAMP + PIH_LIN_DAMP * norm(ov), sw2 = PIH_ANG_DAMP + PIH_ANG_DAMP * norm(ow);
+      const V3 Iw = mul(Iow, ow);
+      const V3 al = mul(Ioi, -cross(ow, Iw) - sw2 * Iw);
+      udot[6] = -sv * ov.x; udot[7] = -sv * ov.y; udot[8] = (real)PIH_GRAVITY_Z - sv * ov.z;
+      udot[9] = al.x; udot[10] = al.y; udot[11] = al.z;
+    }
+    real u[FND];
+#pragma unroll
+    for (int i = 0; i < NJ; i++) u[i] = qd[i] + dt * udot[i];
+    u[6] = ov.x + dt * udot[6]; u[7] = ov.y + dt * udot[7]; u[8] = ov.z + dt * udot[8];
+    u[9] = ow.x + dt * udot[9]; u[10] = ow.y + dt * udot[10]; u[11] = ow.z + dt * udot[11];
+    if (dbg && P.debug) {
+#pragma unroll
+      for (int i = 0; i < FND; i++) dbg[i] = udot[i];
+    }
+    // ---- unit-impulse responses of the arm from the articulated quantities: generalized impulse g (per joint) plus a linear
+    // impulse `f` at point `p` on link `la` (la < 0: none) -> joint velocity changes w[0..5]
+    auto arm_response = [&](int jm, int la, V3 p, V3 f, real* w) {
+      V3 Qa = mk(0, 0, 0), Ql = mk(0, 0, 0); real g[NJ];
+#pragma unroll
+      for (int L = NJ - 1; L >= 0; L--) {
+        if (L == la) { Qa = Qa + cross(p - o[L], f); Ql = Ql + f; }
+        const real gg = (L == jm ? (real)1 : (real)0) + dot(a[L], Qa);
+        g[L] = gg;
+        const real gd = gg * Dinv[L];
+        const V3 qa = Qa - gd * Ua[L], ql = Ql - gd * Ul[L];
+        Qa = qa + cross(r[L], ql); Ql = ql;     // at L = 0 the hand-up goes to the fixed world and is discarded
+      }
+      V3 dw = mk(0, 0, 0), dv = mk(0, 0, 0);
+#pragma unroll
+      for (int L = 0; L < NJ; L++) {
+        const V3 ll = dv + cross(dw, r[L]);
+        const real dq = (g[L] - dot(Ua[L], dw) - dot(Ul[L], ll)) * Dinv[L];
+        w[L] = dq; dw = dw + dq * a[L]; dv = ll;
+      }
+    };
+    // motor rows: W = column j of M^-1; limit rows share it
+    real Wm[NJ][NJ], mdi[NJ], mrhs[NJ], lrl[NJ], lrh[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      arm_response(j, -1, mk(0, 0, 0), mk(0, 0, 0), Wm[j]);
+      mdi[j] = (real)1 / Wm[j][j];
+      mrhs[j] = (vt[j] - u[j]) * mdi[j];
+      const real plo = q[j] - U_LO[j], phi = U_HI[j] - q[j];
+      lrl[j] = ((plo > 0 ? -plo / dt : -P.erp * plo / dt) - u[j]) * mdi[j];
+      lrh[j] = ((phi > 0 ? -phi / dt : -P.erp * phi / dt) + u[j]) * mdi[j];
+    }
+    // contact rows -> lane memory, compacted in slot order (slot i: sphere i vs arm; slot NS + i: sphere i vs table)
+    //   record: 0-5 J arm | 6-11 W arm | 12-14 n | 15-17 (p - o_obj) x n | 18-20 I^-1 ((p - o_obj) x n) | 21 dinv | 22 rhs | 23 slot
+    int nc = 0;
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+      const int i = k < NS ? k : k - NS;
+      bool valid; int la; V3 n, p; real depth;
+      if (k < NS) { valid = clink[i] >= 0; la = clink[i]; n = cn[i]; p = cp[i]; depth = cdepth[i]; }
+      else { depth = sc[i].z - (real)PIH_TABLE_Z - O_SPH_R[i]; valid = depth < P.margin; landed = landed || depth < (real)0.002; la = -1; n = mk(0, 0, 1); p = mk(sc[i].x, sc[i].y, sc[i].z - O_SPH_R[i] - (real)0.5 * depth); }
+      if (valid) {
+        real J[NJ], W[NJ];
+#pragma unroll
+        for (int L = 0; L < NJ; L++) J[L] = L <= la ? -dot(n, cross(a[L], p - o[L])) : (real)0;
+        if (la >= 0) arm_response(-1, la, p, -n, W);
+        else {
+#pragma unroll
+          for (int L = 0; L < NJ; L++) W[L] = 0;
+        }
+        const V3 rxn = cross(p - op, n), wo = mul(Ioi, rxn);
+        real jw = dot(n, n) * ((real)1 / (real)PIH_FLY_OBJ_MASS) + dot(rxn, wo), ju = dot(n, mk(u[6], u[7], u[8])) + dot(rxn, mk(u[9], u[10], u[11]));
+#pragma unroll
+        for (int L = 0; L < NJ; L++) { jw += J[L] * W[L]; ju += J[L] * u[L]; }
+        const real di = (real)1 / jw, pen = depth + P.slop;
+        const real vb = pen > 0 ? -pen / dt : (real)0;      // banana.urdf:9 contact_erp 0: a penetrating contact is stopped, not pushed out [UNVERIFIED]
+        const int b = nc * CW;
+#pragma unroll
+        for (int L = 0; L < NJ; L++) { mem.at(b + L) = J[L]; mem.at(b + 6 + L) = W[L]; }
+        mem.at(b + 12) = n.x; mem.at(b + 13) = n.y; mem.at(b + 14) = n.z; mem.at(b + 15) = rxn.x; mem.at(b + 16) = rxn.y; mem.at(b + 17) = rxn.z;
+        mem.at(b + 18) = wo.x; mem.at(b + 19) = wo.y; mem.at(b + 20) = wo.z; mem.at(b + 21) = di; mem.at(b + 22) = (vb - ju) * di; mem.at(b + 23) = 0;
+        if (dbg && P.debug) { real* d = dbg + 16 + 10 * k; d[0] = 1; d[1] = (real)la; d[2] = p.x; d[3] = p.y; d[4] = p.z; d[5] = n.x; d[6] = n.y; d[7] = n.z; d[8] = depth; d[9] = (real)nc; }
+        nc++;
+      } else if (dbg && P.debug) {
+        real* d = dbg + 16 + 10 * k;
+        for (int t = 0; t < 10; t++) d[t] = 0;
+      }
+    }
+    // ---- sequential impulse: per joint (motor, lower limit, upper limit), then the contact normals
+    real du[FND];
+#pragma unroll
+    for (int i = 0; i < FND; i++) du[i] = 0;
+    real lam_m[NJ], lam_lo[NJ], lam_hi[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { lam_m[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
+    int it = 0;
+    for (; it < P.iters; it++) {
+      real worst = -1;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const real lim = U_EFFORT[j] * dt, di = mdi[j];
+        real dl = mrhs[j] - du[j] * di, sum = med3_(lam_m[j] + dl, -lim, lim);
+        dl = sum - lam_m[j]; lam_m[j] = sum;
+        real tot = dl;
+        { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
+        real dj = du[j] + dl * Wm[j][j];
+        real d2 = lrl[j] - dj * di, s2 = max_(lam_lo[j] + d2, (real)0);
+        d2 = s2 - lam_lo[j]; lam_lo[j] = s2; tot += d2; dj += d2 * Wm[j][j];
+        { const real v = d2 * d2 - P.resid * di * di; worst = v > worst ? v : worst; }
+        real d3 = lrh[j] + dj * di, s3 = max_(lam_hi[j] + d3, (real)0);
+        d3 = s3 - lam_hi[j]; lam_hi[j] = s3; tot -= d3;
+        { const real v = d3 * d3 - P.resid * di * di; worst = v > worst ? v : worst; }
+#pragma unroll
+        for (int k = 0; k < NJ; k++) du[k] += Wm[j][k] * tot;
+      }
+      for (int c = 0; c < nc; c++) {
+        const int b = c * CW;
+        real jd = 0;
+#pragma unroll
+        for (int L = 0; L < NJ; L++) jd += mem.at(b + L) * du[L];
+        const V3 n = mk(mem.at(b + 12), mem.at(b + 13), mem.at(b + 14)), rxn = mk(mem.at(b + 15), mem.at(b + 16), mem.at(b + 17));
+        jd += dot(n, mk(du[6], du[7], du[8])) + dot(rxn, mk(du[9], du[10], du[11]));
+        const real di = mem.at(b + 21), lam = mem.at(b + 23);
+        real dl = mem.at(b + 22) - jd * di;
+        const real sum = max_(lam + dl, (real)0);
+        dl = sum - lam; mem.at(b + 23) = sum;
+#pragma unroll
+        for (int L = 0; L < NJ; L++) du[L] += mem.at(b + 6 + L) * dl;
+        const real im = dl * ((real)1 / (real)PIH_FLY_OBJ_MASS);
+        du[6] += n.x * im; du[7] += n.y * im; du[8] += n.z * im;
+        du[9] += mem.at(b + 18) * dl; du[10] += mem.at(b + 19) * dl; du[11] += mem.at(b + 20) * dl;
+        { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
+      }
+      if (worst <= 0) { it++; break; }
+    }
+    real cf = 0;
+    for (int c = 0; c < nc; c++) cf += mem.at(c * CW + 23);
+    if (dbg && P.debug) {
+      dbg[12] = (real)nc; dbg[13] = (real)it;
+      for (int c = 0; c < nc; c++) dbg[116 + c] = mem.at(c * CW + 23);    // lambda_n of compacted contact c
+    }
+    // ---- integrate
+#pragma unroll
+    for (int i = 0; i < FND; i++) u[i] = clampr(u[i] + du[i], -PIH_MAX_COORD_VEL, PIH_MAX_COORD_VEL);
+#pragma unroll
+    for (int i = 0; i < NJ; i++) { S[PIH_F_QD + i] = u[i]; S[PIH_F_Q + i] = q[i] + dt * u[i]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { S[PIH_F_OVLIN + k] = u[6 + k]; S[PIH_F_OVANG + k] = u[9 + k]; S[PIH_F_OPOS + k] += dt * u[6 + k]; }
+    {
+      const V3 w = mk(u[9], u[10], u[11]);
+      real wn = norm(w), th = wn * dt, sn, cs;
+      sincos_((real)0.5 * th, &sn, &cs);
+      const real k = th > (real)1e-12 ? sn / wn : (real)0.5 * dt;
+      Q4 dq; dq.x = w.x * k; dq.y = w.y * k; dq.z = w.z * k; dq.w = cs;
+      const Q4 qn = q_mul(dq, oq);
+      const real nn = rsqrt_(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+      S[PIH_F_OQUAT] = qn.x * nn; S[PIH_F_OQUAT + 1] = qn.y * nn; S[PIH_F_OQUAT + 2] = qn.z * nn; S[PIH_F_OQUAT + 3] = qn.w * nn;
+    }
+    S[PIH_F_STEPS] += 1;
+    S[PIH_F_CFORCE] = cf / dt; S[PIH_F_NCONTACT] = (real)nc;
+  }
+  // ---- outputs (BUILD-DEFINED): obs = ee xyz + object xyz (world), reward = 1 within 0.1 m of the end effector,
+  // done = caught, landed (a sphere of the object within 2 mm of the table top when the step began; that step still resolves the
+  // impact) or max_episode_steps
+  const V3 ee = ee_position(S + PIH_F_Q);
+  const V3 d = ld3(S + PIH_F_OPOS) - ee;
+  const real rew = norm(d) < (real)0.1 ? (real)1 : (real)0;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < PIH_F_DONE; i++) bad = bad || !finite_small(S[i]);
+  if (!frozen && (rew > 0 || landed || S[PIH_F_STEPS] >= (real)P.maxsteps)) S[PIH_F_DONE] = 1;
+  S[PIH_F_EE] = ee.x + S[PIH_F_OFFSET]; S[PIH_F_EE + 1] = ee.y + S[PIH_F_OFFSET + 1]; S[PIH_F_EE + 2] = ee.z + S[PIH_F_OFFSET + 2];
+  obs[0] = S[PIH_F_EE]; obs[1] = S[PIH_F_EE + 1]; obs[2] = S[PIH_F_EE + 2];
+  obs[3] = S[PIH_F_OPOS] + S[PIH_F_OFFSET]; obs[4] = S[PIH_F_OPOS + 1] + S[PIH_F_OFFSET + 1]; obs[5] = S[PIH_F_OPOS + 2] + S[PIH_F_OFFSET + 2];
+  *reward = rew; *done = (unsigned char)((S[PIH_F_DONE] != 0 || bad) ? 1 : 0);
+  if (bad || (P.autoreset && S[PIH_F_DONE] != 0)) {
+    if (bad) {
+      S[PIH_F_RNG] = (finite_small(S[PIH_F_RNG]) && S[PIH_F_RNG] >= 0 && S[PIH_F_RNG] < (real)16777216) ? S[PIH_F_RNG] : (real)0;
+      S[PIH_F_RNG_HI] = (finite_small(S[PIH_F_RNG_HI]) && S[PIH_F_RNG_HI] >= 0 && S[PIH_F_RNG_HI] < (real)16777216) ? S[PIH_F_RNG_HI] : (real)0;
+      const real nb = S[PIH_F_SPARE]; S[PIH_F_SPARE] = (finite_small(nb) && nb >= 0 ? nb : (real)0) + 1;
+    }
+    fly::reset_state(S, P, env_global);
+    if (bad && !P.autoreset) { S[PIH_F_DONE] = 1; S[PIH_F_INVALID] = 1; }
+  }
+}
+
+}  // namespace fly
+}  // namespace pih

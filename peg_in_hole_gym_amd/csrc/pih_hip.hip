@@ -8,6 +8,7 @@
 #include <vector>
 #include "pih_device.h"
 #include "pih_render.h"
+#include "pih_fly.h"
 
 using namespace pih;
 
@@ -207,6 +208,68 @@ __global__ void pih_gather_kernel(const float* __restrict__ state, float* __rest
   out[idx] = state[(size_t)e * PIH_STATE_WORDS + word0 + k];
 }
 
+// ------------------------------------------------------------------------------------------------ 'random-fly' task kernels
+// One env per LANE (pih_fly.h).  state: float[PIH_FLY_STATE_WORDS][n] (structure-of-arrays: word w of the 64 envs of a wave is
+// one coalesced 256 B segment).  LDS: the per-lane contact rows, [word][lane].
+__global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
+                                                             float* __restrict__ obs, float* __restrict__ reward,
+                                                             unsigned char* __restrict__ done, float* __restrict__ dbg, int n) {
+  __shared__ float lanemem[fly::LANE_WORDS * 64];
+  const int env = blockIdx.x * 64 + threadIdx.x;
+  if (env >= n) return;
+  float S[fly::SW];
+#pragma unroll
+  for (int w = 0; w < fly::SW; w++) S[w] = state[(size_t)w * n + env];
+  float a[PIH_FLY_ACTION_DIM] = {0, 0, 0, 0, 0, 0};
+  if (actions) {
+#pragma unroll
+    for (int k = 0; k < PIH_FLY_ACTION_DIM; k++) a[k] = actions[(size_t)env * PIH_FLY_ACTION_DIM + k];
+  }
+  float o[PIH_FLY_OBS_DIM], r; unsigned char d;
+  fly::LaneMem mem; mem.p = lanemem + threadIdx.x; mem.stride = 64;
+  fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
+#pragma unroll
+  for (int w = 0; w < fly::SW; w++) state[(size_t)w * n + env] = S[w];
+  if (obs) {
+#pragma unroll
+    for (int k = 0; k < PIH_FLY_OBS_DIM; k++) obs[(size_t)env * PIH_FLY_OBS_DIM + k] = o[k];
+  }
+  if (reward) reward[env] = r;
+  if (done) done[env] = d;
+}
+
+__global__ void __launch_bounds__(64) pih_fly_reset_kernel(Params P, float* __restrict__ state, const unsigned char* __restrict__ mask, int hard, int n) {
+  const int env = blockIdx.x * 64 + threadIdx.x;
+  if (env >= n || (mask && !mask[env])) return;
+  float S[fly::SW];
+#pragma unroll
+  for (int w = 0; w < fly::SW; w++) S[w] = state[(size_t)w * n + env];
+  if (hard) { S[PIH_F_RNG] = 0; S[PIH_F_RNG_HI] = 0; S[PIH_F_SPARE] = 0; }
+  fly::reset_state(S, P, P.env0 + env);
+#pragma unroll
+  for (int w = 0; w < fly::SW; w++) state[(size_t)w * n + env] = S[w];
+}
+
+// env-major float[n, W]  <->  structure-of-arrays float[W][n]
+__global__ void pih_soa_to_aos_kernel(const float* __restrict__ soa, float* __restrict__ aos, int n, int W, int word0, int nwords) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * nwords) return;
+  const int e = idx / nwords, k = idx - e * nwords;
+  aos[idx] = soa[(size_t)(word0 + k) * n + e];
+  (void)W;
+}
+__global__ void pih_aos_to_soa_kernel(const float* __restrict__ aos, float* __restrict__ soa, int n, int W) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * W) return;
+  const int w = idx / n, e = idx - w * n;
+  soa[idx] = aos[(size_t)e * W + w];
+}
+__global__ void pih_fly_init_offsets_kernel(float* __restrict__ state, const float* __restrict__ offsets, int n) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= n) return;
+  for (int k = 0; k < 3; k++) state[(size_t)(PIH_F_OFFSET + k) * n + e] = offsets ? offsets[3 * e + k] : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 constexpr size_t EV_POOL = 1024;   // timing event triples kept before they are folded into the running sums
 struct EvTriple { hipEvent_t a, b, c; };
@@ -214,6 +277,8 @@ struct pih_handle {
   pih_config cfg;
   Params P;
   int device = 0;
+  bool fly = false;         // PIH_TASK_RANDOM_FLY: structure-of-arrays state, one env per lane
+  int words = PIH_STATE_WORDS;
   float* state = nullptr;
   float* dbg = nullptr;
   float* ovf = nullptr;     // spill area for contacts beyond the LDS-resident CL (rarely touched)
@@ -279,6 +344,12 @@ void pih_default_config(pih_config* c) {
   c->dv = 2.0f / 240.0f;
 }
 int pih_abi_version(void) { return PIH_ABI_VERSION; }
+int pih_task_dims(int task_id, int32_t out[3]) {
+  if (!out) return -2;
+  if (task_id == PIH_TASK_PEG_IN_HOLE) { out[0] = PIH_ACTION_DIM; out[1] = PIH_OBS_DIM; out[2] = PIH_STATE_WORDS; return 0; }
+  if (task_id == PIH_TASK_RANDOM_FLY) { out[0] = PIH_FLY_ACTION_DIM; out[1] = PIH_FLY_OBS_DIM; out[2] = PIH_FLY_STATE_WORDS; return 0; }
+  return -2;
+}
 
 int pih_destroy(pih_handle* h) {
   if (!h) return 0;
@@ -295,17 +366,25 @@ int pih_destroy(pih_handle* h) {
 // allocation + first reset; on any failure the caller (pih_create) destroys the half-built handle
 static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
   const pih_config* cfg = &h->cfg;
-  size_t nb = (size_t)cfg->n_envs * PIH_STATE_WORDS * sizeof(float);
+  size_t nb = (size_t)cfg->n_envs * h->words * sizeof(float);
   HIPCHK(h, hipMalloc(&h->state, nb));
   HIPCHK(h, hipMemset(h->state, 0, nb));
-  HIPCHK(h, hipMalloc(&h->ovf, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
-  HIPCHK(h, hipMemset(h->ovf, 0, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
-  if (cfg->schedule) HIPCHK(h, hipMalloc(&h->order, (size_t)cfg->n_envs * sizeof(int)));
   if (cfg->debug) { HIPCHK(h, hipMalloc(&h->dbg, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); HIPCHK(h, hipMemset(h->dbg, 0, (size_t)cfg->n_envs * PIH_DEBUG_WORDS * sizeof(float))); }
   if (offsets_host) {
     HIPCHK(h, hipMalloc(offd, (size_t)cfg->n_envs * 3 * sizeof(float)));
     HIPCHK(h, hipMemcpy(*offd, offsets_host, (size_t)cfg->n_envs * 3 * sizeof(float), hipMemcpyHostToDevice));
   }
+  if (h->fly) {
+    const int nb64 = (cfg->n_envs + 63) / 64;
+    hipLaunchKernelGGL(pih_fly_init_offsets_kernel, dim3(nb64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
+    hipLaunchKernelGGL(pih_fly_reset_kernel, dim3(nb64), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0, cfg->n_envs);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipDeviceSynchronize());
+    return 0;
+  }
+  HIPCHK(h, hipMalloc(&h->ovf, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
+  HIPCHK(h, hipMemset(h->ovf, 0, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
+  if (cfg->schedule) HIPCHK(h, hipMalloc(&h->order, (size_t)cfg->n_envs * sizeof(int)));
   hipLaunchKernelGGL(pih_init_offsets_kernel, dim3((cfg->n_envs + 63) / 64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
   hipLaunchKernelGGL(pih_reset_kernel, dim3(cfg->n_envs), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0);
   HIPCHK(h, hipGetLastError());
@@ -315,12 +394,13 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
 
 int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** out) {
   if (!cfg || !out || cfg->n_envs <= 0) { g_err = "pih_create: bad arguments"; return -2; }
-  if (cfg->task_id != PIH_TASK_PEG_IN_HOLE) { g_err = "pih_create: unknown task_id"; return -2; }
+  if (cfg->task_id != PIH_TASK_PEG_IN_HOLE && cfg->task_id != PIH_TASK_RANDOM_FLY) { g_err = "pih_create: unknown task_id"; return -2; }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) { g_err = "pih_create: no HIP device (this library has no CPU path)"; return -3; }
   pih_handle* h = new pih_handle;
   h->cfg = *cfg; h->P = make_params(cfg);
+  h->fly = cfg->task_id == PIH_TASK_RANDOM_FLY; h->words = h->fly ? PIH_FLY_STATE_WORDS : PIH_STATE_WORDS;
   float* offd = nullptr;
   int rc = -1;
   if (hipGetDevice(&h->device) == hipSuccess) rc = create_impl(h, offsets_host, &offd);
@@ -334,7 +414,8 @@ int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** ou
 int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, void* stream) {
   if (!h) return -2;
   PIH_ENTER(h);
-  hipLaunchKernelGGL(pih_reset_kernel, dim3(h->cfg.n_envs), dim3(64), 0, (hipStream_t)stream, h->P, h->state, mask_dev, hard != 0);
+  if (h->fly) hipLaunchKernelGGL(pih_fly_reset_kernel, dim3((h->cfg.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, h->state, mask_dev, hard != 0, h->cfg.n_envs);
+  else hipLaunchKernelGGL(pih_reset_kernel, dim3(h->cfg.n_envs), dim3(64), 0, (hipStream_t)stream, h->P, h->state, mask_dev, hard != 0);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -357,6 +438,13 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
     t = &h->ev[h->ev_used++];
     HIPCHK(h, hipEventRecord(t->a, s));
   }
+  if (h->fly) {   // one launch: controller + physics, one env per lane
+    if (t) HIPCHK(h, hipEventRecord(t->b, s));
+    hipLaunchKernelGGL(pih_fly_step_kernel, dim3((h->cfg.n_envs + 63) / 64), dim3(64), 0, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs);
+    if (t) HIPCHK(h, hipEventRecord(t->c, s));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(pih_pre_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs);
   if (t) HIPCHK(h, hipEventRecord(t->b, s));
   hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, obs, reward, done, h->dbg, h->ovf, h->order);
@@ -367,14 +455,14 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
 
 int pih_step(pih_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
   if (!h) return -2;
-  if (h->cfg.mode == 0 && !actions_dev) { h->err = "pih_step: actions_dev is NULL in action mode"; return -2; }
+  if ((h->cfg.mode == 0 || h->fly) && !actions_dev) { h->err = "pih_step: actions_dev is NULL in action mode"; return -2; }
   PIH_ENTER(h);
   return launch_step(h, actions_dev, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
 }
 
 int pih_step_n(pih_handle* h, int k, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
   if (!h || k < 0) return -2;
-  if (h->cfg.mode == 0 && !actions_dev) { h->err = "pih_step_n: actions_dev is NULL in action mode"; return -2; }
+  if ((h->cfg.mode == 0 || h->fly) && !actions_dev) { h->err = "pih_step_n: actions_dev is NULL in action mode"; return -2; }
   PIH_ENTER(h);
   for (int i = 0; i < k; i++) { int r = launch_step(h, actions_dev, obs_dev, reward_dev, done_dev, (hipStream_t)stream); if (r) return r; }
   return 0;
@@ -385,6 +473,21 @@ int pih_get_state(pih_handle* h, int field, void* out_dev, void* stream) {
   PIH_ENTER(h);
   hipStream_t s = (hipStream_t)stream;
   const int n = h->cfg.n_envs;
+  if (h->fly) {
+    int w0 = 0, nw = 0;
+    switch (field) {
+      case PIH_FIELD_STATE: w0 = 0; nw = PIH_FLY_STATE_WORDS; break;
+      case PIH_FIELD_CONTACT_FORCE: w0 = PIH_F_CFORCE; nw = 1; break;
+      case PIH_FIELD_EE_POS: w0 = PIH_F_EE; nw = 3; break;
+      case PIH_FIELD_DEBUG:
+        if (!h->dbg) { h->err = "pih_get_state: debug buffer not enabled (config.debug = 0)"; return -4; }
+        HIPCHK(h, hipMemcpyAsync(out_dev, h->dbg, (size_t)n * PIH_DEBUG_WORDS * sizeof(float), hipMemcpyDeviceToDevice, s)); return 0;
+      default: h->err = "pih_get_state: field not available for the random-fly task"; return -2;
+    }
+    hipLaunchKernelGGL(pih_soa_to_aos_kernel, dim3((n * nw + 255) / 256), dim3(256), 0, s, h->state, (float*)out_dev, n, PIH_FLY_STATE_WORDS, w0, nw);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+  }
   switch (field) {
     case PIH_FIELD_STATE: HIPCHK(h, hipMemcpyAsync(out_dev, h->state, (size_t)n * PIH_STATE_WORDS * sizeof(float), hipMemcpyDeviceToDevice, s)); return 0;
     case PIH_FIELD_TIP_POSE: hipLaunchKernelGGL(pih_gather_kernel, dim3((n * 7 + 255) / 256), dim3(256), 0, s, h->state, (float*)out_dev, n, (int)PIH_S_TIP, 7); break;
@@ -403,6 +506,12 @@ int pih_set_state(pih_handle* h, int field, const void* in_dev, void* stream) {
   if (!h || !in_dev) return -2;
   if (field != PIH_FIELD_STATE) { h->err = "pih_set_state: only PIH_FIELD_STATE is writable"; return -2; }
   PIH_ENTER(h);
+  if (h->fly) {
+    const int n = h->cfg.n_envs;
+    hipLaunchKernelGGL(pih_aos_to_soa_kernel, dim3((n * PIH_FLY_STATE_WORDS + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)in_dev, h->state, n, PIH_FLY_STATE_WORDS);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+  }
   HIPCHK(h, hipMemcpyAsync(h->state, in_dev, (size_t)h->cfg.n_envs * PIH_STATE_WORDS * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
@@ -428,6 +537,7 @@ int pih_render(pih_handle* h, float* out_dev, int width, int height, int env_beg
     if (h) h->err = "pih_render: bad arguments";
     return -2;
   }
+  if (h->fly) { h->err = "pih_render: the wrist camera belongs to the peg-in-hole task"; return -2; }
   if ((reinterpret_cast<uintptr_t>(out_dev) & 15) != 0) { h->err = "pih_render: out_dev must be 16-byte aligned"; return -2; }
   PIH_ENTER(h);
   // every workgroup runs the forward kinematics of its env once: few strips per env when the batch alone gives the chip
@@ -448,6 +558,7 @@ int pih_grasp_labels(pih_handle* h, float* out_dev, float* meta_dev, int size, i
     if (h) h->err = "pih_grasp_labels: bad arguments";
     return -2;
   }
+  if (h->fly) { h->err = "pih_grasp_labels: the grasp labels belong to the peg-in-hole task"; return -2; }
   PIH_ENTER(h);
   hipLaunchKernelGGL(pih_labels_kernel, dim3((size * size + 1023) / 1024, env_count), dim3(256), 0, (hipStream_t)stream, h->state, out_dev, meta_dev, env_begin, size);
   HIPCHK(h, hipGetLastError());

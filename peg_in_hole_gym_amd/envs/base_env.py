@@ -2,12 +2,23 @@
 envs/base_env.py:13-98, backed by the batched HIP step instead of one BulletClient."""
 import numpy as np
 
-from .peg_in_hole import PegInHole
+from .peg_in_hole import PegInHole, RandomFly
 from .utils import MultiAgentActionSpace, MultiAgentObservationSpace, env_offsets
 
+# name -> task descriptor (envs/base_env.py:9-11); a descriptor carries the kernel task id (include/pih.h PIH_TASK_*)
 TASK_LIST = {
     'peg-in-hole': PegInHole,
+    'random-fly': RandomFly,
 }
+
+
+def task_backend_cfg(task, args):
+    """pih_config fields that select and configure a registered task"""
+    sub = TASK_LIST[task]
+    kw = {"task_id": sub.task_id}
+    kw.update(sub.default_cfg)
+    kw.update(sub.cfg_from_args(args))
+    return kw
 
 _MODES = {'action': 0, 'scripted': 1}
 GRASP_IMG_STEP = 540       # physics steps before the state machine enters state 2 (60 + 480, envs/peg_in_hole.py:206-212,263)
@@ -70,11 +81,14 @@ class BaseEnv(object):
         self.observation_space = MultiAgentObservationSpace([self.sub_env.observation_space for _ in range(task_num)])
         factory = backend_factory or _default_backend
         kw = dict(mode=_MODES[mode], seed=seed, env_index0=env_index0, auto_reset=0)
+        kw.update(task_backend_cfg(task, args))
         if backend_factory is None:
             kw["device"] = device
         if mode == 'scripted':
+            assert task == 'peg-in-hole', "the scripted grasp-and-insert episode belongs to the peg-in-hole task"
             kw["dv"] = 0.05             # envs/peg_in_hole.py:259
         kw.update(cfg)
+        self._adim = self.sub_env.action_space.shape[0]
         self._backend = factory(task_num, env_offsets(offset, task_num), **kw)
 
     # --- reference API -------------------------------------------------------------------------------------------
@@ -92,7 +106,7 @@ class BaseEnv(object):
     def step(self, action):
         if not hasattr(self, "dones"):
             raise AttributeError("'BaseEnv' object has no attribute 'dones' (call reset() before step(), as in the reference)")
-        a = np.asarray([np.asarray(x, dtype=np.float32) for x in action], dtype=np.float32).reshape(self.task_num, 4)
+        a = np.asarray([np.asarray(x, dtype=np.float32) for x in action], dtype=np.float32).reshape(self.task_num, self._adim)
         obs, rew, done = self._step_backend(a)
         for i in range(self.task_num):
             if not self.dones[i]:       # finished agents keep their last values (envs/base_env.py:62,66)
@@ -140,10 +154,19 @@ class BaseEnv(object):
         return _to_numpy(obs).astype(np.float32), _to_numpy(rew), _to_numpy(done)
 
     def _obs_after_reset(self):
-        st = _to_numpy(self._backend.state())
-        fk = _to_numpy(self._backend.ee_position()) if hasattr(self._backend, "ee_position") else None
-        out = []
-        for i in range(self.task_num):
-            ee = fk[i] if fk is not None else np.zeros(3)
-            out.append(np.array([st[i, 7], st[i, 8], ee[0], ee[1], ee[2]], dtype=np.float32))
-        return out
+        return obs_after_reset(self._backend, self.task, self.task_num)
+
+
+def obs_after_reset(backend, task, n):
+    """The declared observation vector right after reset (the reference returns [] there, envs/peg_in_hole.py:274)"""
+    st = _to_numpy(backend.state())
+    if task == 'random-fly':
+        from .. import _lib
+        return [np.concatenate([st[i, _lib.F_EE:_lib.F_EE + 3], st[i, _lib.F_OPOS:_lib.F_OPOS + 3] + st[i, _lib.F_OFFSET:_lib.F_OFFSET + 3]]).astype(np.float32) for i in range(n)]
+    fk = _to_numpy(backend.ee_position()) if hasattr(backend, "ee_position") else None
+    out = []
+    for i in range(n):
+        ee = fk[i] if fk is not None else np.zeros(3)
+        out.append(np.array([st[i, 7], st[i, 8], ee[0], ee[1], ee[2]], dtype=np.float32))
+    return out
+

@@ -3,7 +3,8 @@ nesting (envs/base_env_mp.py:7-87).  The reference forks mp_num processes and pi
 Queue(1) pairs; here every agent is one wavefront of ONE batched launch, so there are no worker processes at all."""
 import numpy as np
 
-from .base_env import IMG_SHAPE, TASK_LIST, _MODES, _default_backend, _reset_backend, _to_numpy, scripted_episode
+from .base_env import (IMG_SHAPE, TASK_LIST, _MODES, _default_backend, _reset_backend, _to_numpy, obs_after_reset, scripted_episode,
+                       task_backend_cfg)
 from .utils import (MultiAgentActionSpace, MultiAgentObservationSpace, MPMultiAgentActionSpace,
                     MPMultiAgentObservationSpace, env_offsets)
 
@@ -33,9 +34,12 @@ class BaseEnvMp(object):
         offs = np.tile(env_offsets(offset, sub_num), (mp_num, 1))     # every worker world lays its agents out the same way
         factory = backend_factory or _default_backend
         kw = dict(mode=_MODES[mode], seed=seed, env_index0=env_index0, auto_reset=0)
+        kw.update(task_backend_cfg(task, args))
+        self._adim = sub.action_space.shape[0]
         if backend_factory is None:
             kw["device"] = device
         if mode == 'scripted':
+            assert task == 'peg-in-hole', "the scripted grasp-and-insert episode belongs to the peg-in-hole task"
             kw["dv"] = 0.05
         kw.update(cfg)
         self._backend = factory(self.n, offs, **kw)
@@ -57,16 +61,13 @@ class BaseEnvMp(object):
         self.rewards = [[0. for _ in range(self.sub_num)] for _ in range(self.mp_num)]
         self.infos = [[{} for _ in range(self.sub_num)] for _ in range(self.mp_num)]
         self.dones = [[False for _ in range(self.sub_num)] for _ in range(self.mp_num)]
-        st = _to_numpy(self._backend.state())
-        ee = _to_numpy(self._backend.ee_position()) if hasattr(self._backend, "ee_position") else np.zeros((self.n, 3))
-        flat = [np.array([st[i, 7], st[i, 8], ee[i, 0], ee[i, 1], ee[i, 2]], dtype=np.float32) for i in range(self.n)]
-        self.observations = self._nest(flat)
+        self.observations = self._nest(obs_after_reset(self._backend, self.task, self.n))
         return self.observations
 
     def step(self, action):
         if not hasattr(self, "dones"):
             raise AttributeError("'BaseEnvMp' object has no attribute 'dones' (call reset() before step(), as in the reference)")
-        a = np.asarray([[np.asarray(x, dtype=np.float32) for x in row] for row in action], dtype=np.float32).reshape(self.n, 4)
+        a = np.asarray([[np.asarray(x, dtype=np.float32) for x in row] for row in action], dtype=np.float32).reshape(self.n, self._adim)
         be = self._backend
         wrap = a
         try:

@@ -10,9 +10,12 @@ from . import _lib
 
 
 class PihVecEnv:
-    """N independent Panda + pipe + hole worlds on one MI355X, one wavefront per world.
+    """N independent worlds of one task on one MI355X.
 
-    step(actions[N,4]) -> obs[N,5] (finger1, finger2, ee xyz; envs/peg_in_hole.py:13), reward[N], done[N]
+    task_id 0 ('peg-in-hole', default): Panda + pipe + hole, one wavefront per world;
+        step(actions[N,4]) -> obs[N,5] (finger1, finger2, ee xyz; envs/peg_in_hole.py:13), reward[N], done[N]
+    task_id 1 ('random-fly'): UR5 + one free-flying object, one LANE per world;
+        step(actions[N,6] = ee target xyz + euler rpy, envs/utils.py:70-72) -> obs[N,6] (ee xyz, object xyz), reward[N], done[N]
     mirrors BaseEnv.step (envs/base_env.py:60-75) for every agent at once; see include/pih.h for what each call replaces.
     """
 
@@ -23,6 +26,9 @@ class PihVecEnv:
         self.n = int(n_envs)
         self.device = torch.device(device)
         self.cfg = _lib.default_config(n_envs=self.n, **cfg)
+        self.task_id = int(self.cfg.task_id)
+        self.action_dim, self.obs_dim, self.state_words = _lib.task_dims(self.task_id)
+        self._invalid_word = _lib.F_INVALID if self.task_id == _lib.TASK_RANDOM_FLY else _lib.S_INVALID
         off = None
         if offsets is not None:
             off = np.ascontiguousarray(np.asarray(offsets, dtype=np.float32).reshape(self.n, 3))
@@ -31,7 +37,7 @@ class PihVecEnv:
             rc = self.L.pih_create(C.byref(self.cfg), off.ctypes.data if off is not None else None, C.byref(self.h))
         if rc != 0:
             raise _lib.PihError("pih_create failed (%d): %s" % (rc, self.L.pih_last_error(None).decode()))
-        self.obs = torch.zeros(self.n, _lib.OBS_DIM, device=self.device)
+        self.obs = torch.zeros(self.n, self.obs_dim, device=self.device)
         self.reward = torch.zeros(self.n, device=self.device)
         self.done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
 
@@ -66,13 +72,13 @@ class PihVecEnv:
 
     def invalid(self):
         """uint8-like [n]: envs whose state became non-finite with auto_reset = 0 (re-initialised, done, frozen until reset)."""
-        return self.state()[:, _lib.S_INVALID] != 0
+        return self.state()[:, self._invalid_word] != 0
 
     def step(self, actions):
         a = None
         if actions is not None:
             a = actions.to(device=self.device, dtype=torch.float32).contiguous()
-            assert a.shape == (self.n, _lib.ACTION_DIM), a.shape
+            assert a.shape == (self.n, self.action_dim), a.shape
         with torch.cuda.device(self.device):
             self._chk(self.L.pih_step(self.h, a.data_ptr() if a is not None else None, self.obs.data_ptr(), self.reward.data_ptr(),
                                       self.done.data_ptr(), self._stream()), "pih_step")
@@ -94,11 +100,11 @@ class PihVecEnv:
         return out
 
     def state(self):
-        return self._get(_lib.FIELD_STATE, (self.n, _lib.STATE_WORDS))
+        return self._get(_lib.FIELD_STATE, (self.n, self.state_words))
 
     def set_state(self, s):
         s = s.to(device=self.device, dtype=torch.float32).contiguous()
-        assert s.shape == (self.n, _lib.STATE_WORDS)
+        assert s.shape == (self.n, self.state_words)
         with torch.cuda.device(self.device):
             self._chk(self.L.pih_set_state(self.h, _lib.FIELD_STATE, s.data_ptr(), self._stream()), "pih_set_state")
 

@@ -55,6 +55,14 @@ def lib(prec):
         L.emul_set_dv.argtypes = [C.c_void_p, C.c_double]
         L.emul_ik.argtypes = [C.POINTER(PihConfig), dp, dp, dp, dp]
         L.emul_ik_ur5.argtypes = [C.POINTER(PihConfig), dp, dp, dp, dp]
+        L.emul_fly_create.restype = C.c_void_p
+        L.emul_fly_create.argtypes = [C.POINTER(PihConfig), dp, C.c_double]
+        L.emul_fly_destroy.argtypes = [C.c_void_p]
+        L.emul_fly_reset.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
+        L.emul_fly_step.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_uint8)]
+        L.emul_fly_get_state.argtypes = [C.c_void_p, dp]
+        L.emul_fly_set_state.argtypes = [C.c_void_p, dp]
+        L.emul_fly_get_debug.argtypes = [C.c_void_p, dp]
         _libs[prec] = L
     return _libs[prec]
 
@@ -109,3 +117,39 @@ def ik_ur5(q0, tpos, tquat, prec="f64", cfg=None):
     q0 = np.ascontiguousarray(q0, dtype=np.float64); tp = np.ascontiguousarray(tpos, dtype=np.float64)
     tq = np.ascontiguousarray(tquat, dtype=np.float64); out = np.zeros(6)
     lib(prec).emul_ik_ur5(C.byref(cfg), _dp(q0), _dp(tp), _dp(tq), _dp(out)); return out
+
+
+class EmulFly:
+    """Host build of the random-fly per-lane step (pih_fly.h), one env after the other."""
+
+    def __init__(self, n_envs=1, prec="f64", offsets=None, dt=1.0 / 240.0, **kw):
+        self.L = lib(prec)
+        kw.setdefault("max_episode_steps", 480)
+        kw.setdefault("contact_margin", 0.02)
+        self.cfg = default_config(n_envs=n_envs, task_id=1, dt=dt, **kw)
+        self.n = n_envs
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64).reshape(n_envs, 3)
+        self.h = self.L.emul_fly_create(C.byref(self.cfg), _dp(off) if off is not None else None, float(dt))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.emul_fly_destroy(self.h); self.h = None
+
+    def reset(self, mask=None, hard_reset=False):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self.L.emul_fly_reset(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None, int(hard_reset))
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n, 6)
+        obs = np.zeros((self.n, 6)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.uint8)
+        self.L.emul_fly_step(self.h, _dp(a), _dp(obs), _dp(rew), done.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return obs, rew, done
+
+    def get_state(self):
+        s = np.zeros((self.n, 48)); self.L.emul_fly_get_state(self.h, _dp(s)); return s
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64).reshape(self.n, 48); self.L.emul_fly_set_state(self.h, _dp(s))
+
+    def get_debug(self):
+        d = np.zeros((self.n, DEBUG_WORDS)); self.L.emul_fly_get_debug(self.h, _dp(d)); return d

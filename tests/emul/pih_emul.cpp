@@ -4,6 +4,7 @@
 // equivalence) and in float (fp32 sensitivity).  It is NOT part of the product: libpih_hip.so contains no host path.
 #define PIH_HOST_EMUL 1
 #include "../../peg_in_hole_gym_amd/csrc/pih_device.h"
+#include "../../peg_in_hole_gym_amd/csrc/pih_fly.h"
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -83,4 +84,43 @@ void emul_ik_ur5(const pih_config* c, const double* q0, const double* tpos, cons
   ik_chain<Ur5Chain>(w, ikT, P, q, mk((real)tpos[0], (real)tpos[1], (real)tpos[2]), tq, qo);
   for (int i = 0; i < 6; i++) qout[i] = qo[i];
 }
+
+// ---- 'random-fly' task (pih_fly.h): the same per-lane scalar code the GPU runs, one env after the other
+struct EmulFly { Params P; int n; std::vector<real> state, dbg; };
+void* emul_fly_create(const pih_config* c, const double* offsets, double dt) {
+  EmulFly* e = new EmulFly;
+  e->P = make_params(c); e->n = c->n_envs;
+  if (dt > 0) e->P.dt = (real)dt;
+  e->state.assign((size_t)e->n * PIH_FLY_STATE_WORDS, 0); e->dbg.assign((size_t)e->n * PIH_DEBUG_WORDS, 0);
+  for (int i = 0; i < e->n; i++) {
+    real* S = &e->state[(size_t)i * PIH_FLY_STATE_WORDS];
+    if (offsets) for (int k = 0; k < 3; k++) S[PIH_F_OFFSET + k] = (real)offsets[3 * i + k];
+    fly::reset_state(S, e->P, e->P.env0 + i);
+  }
+  return e;
+}
+void emul_fly_destroy(void* h) { delete (EmulFly*)h; }
+void emul_fly_reset(void* h, const unsigned char* mask, int hard) {
+  EmulFly* e = (EmulFly*)h;
+  for (int i = 0; i < e->n; i++) if (!mask || mask[i]) {
+    real* S = &e->state[(size_t)i * PIH_FLY_STATE_WORDS];
+    if (hard) { S[PIH_F_RNG] = 0; S[PIH_F_RNG_HI] = 0; S[PIH_F_SPARE] = 0; }
+    fly::reset_state(S, e->P, e->P.env0 + i);
+  }
+}
+void emul_fly_step(void* h, const double* actions, double* obs, double* reward, unsigned char* done) {
+  EmulFly* e = (EmulFly*)h;
+  static real lanemem[fly::LANE_WORDS];
+  for (int i = 0; i < e->n; i++) {
+    real a[6], o[6], r; unsigned char d;
+    for (int k = 0; k < 6; k++) a[k] = (real)actions[6 * i + k];
+    fly::LaneMem mem; mem.p = lanemem; mem.stride = 1;
+    fly::step_env(&e->state[(size_t)i * PIH_FLY_STATE_WORDS], e->P, e->P.env0 + i, a, o, &r, &d, mem, &e->dbg[(size_t)i * PIH_DEBUG_WORDS]);
+    for (int k = 0; k < 6; k++) obs[6 * i + k] = o[k];
+    reward[i] = r; done[i] = d;
+  }
+}
+void emul_fly_get_state(void* h, double* out) { EmulFly* e = (EmulFly*)h; for (size_t i = 0; i < e->state.size(); i++) out[i] = e->state[i]; }
+void emul_fly_set_state(void* h, const double* in) { EmulFly* e = (EmulFly*)h; for (size_t i = 0; i < e->state.size(); i++) e->state[i] = (real)in[i]; }
+void emul_fly_get_debug(void* h, double* out) { EmulFly* e = (EmulFly*)h; for (size_t i = 0; i < e->dbg.size(); i++) out[i] = e->dbg[i]; }
 }

@@ -6,12 +6,14 @@ from oracle import oracle as O
 
 
 class OracleBackend:
-    def __init__(self, n, offsets=None, mode=0, seed=0, env_index0=0, auto_reset=0, device=None, **cfg):
+    def __init__(self, n, offsets=None, mode=0, seed=0, env_index0=0, auto_reset=0, device=None, task_id=0, **cfg):
         kw = dict(mode=mode, seed=seed, env_index0=env_index0, auto_reset=auto_reset)
         kw.update(cfg)
         self.n = n
+        self.task_id = task_id
+        self.adim = 6 if task_id == 1 else 4
         self.offsets = np.zeros((n, 3)) if offsets is None else np.asarray(offsets, dtype=float).reshape(n, 3)
-        self.o = O.Oracle(n, offsets=self.offsets, **kw)
+        self.o = (O.FlyOracle if task_id == 1 else O.Oracle)(n, offsets=self.offsets, **kw)
         self._obs = None
 
     def reset(self, mask=None, hard_reset=False):
@@ -21,10 +23,10 @@ class OracleBackend:
         self.o.reseed(seed)
 
     def invalid(self):
-        return self.o.get_state()[:, 112] != 0
+        return self.o.get_state()[:, 39 if self.task_id == 1 else 112] != 0
 
     def step(self, actions):
-        a = np.asarray(actions, dtype=np.float64).reshape(self.n, 4)
+        a = np.asarray(actions, dtype=np.float64).reshape(self.n, self.adim)
         obs, rew, done = self.o.step(a)
         self._obs = obs
         return obs.astype(np.float32), rew.astype(np.float32), done
@@ -37,6 +39,8 @@ class OracleBackend:
         return out[0].astype(np.float32), out[1].astype(np.float32), out[2]
 
     def state(self):
+        if self.task_id == 1:
+            return self.o.get_state()
         s = np.zeros((self.n, 256))
         s[:, :128] = self.o.get_state()
         return s

@@ -66,7 +66,7 @@ def test_done_agents_are_frozen_like_the_reference():
 
 def test_constructor_asserts_like_the_reference():
     with pytest.raises(AssertionError):
-        BaseEnv(task="random-fly", backend_factory=factory)                 # not in TASK_LIST (envs/base_env.py:16)
+        BaseEnv(task="charge-board", backend_factory=factory)               # not in TASK_LIST (envs/base_env.py:16)
     with pytest.raises(AssertionError):
         BaseEnv(task="peg-in-hole", task_num=2, offset=[0, 0, 0], backend_factory=factory)   # envs/base_env.py:17
 

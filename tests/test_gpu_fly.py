@@ -1,0 +1,153 @@
+"""GPU parity tests of the 'random-fly' task (BASELINE configs[4]: UR5 + free-flying object, 4096 envs): the HIP path (one env
+per lane, pih_fly.h) through the C ABI against the fp64 oracle on the same seeded inputs.  Tolerances: positions 1e-3 m / forces
+1e-2 N relative as in north_star; one-step errors are asserted far tighter.  PARITY UNPINNED vs PyBullet."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DT = 1.0 / 120.0
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch
+
+
+def _gpu(n, **kw):
+    from peg_in_hole_gym_amd.vec_env import PihVecEnv
+    kw.setdefault("max_episode_steps", 480); kw.setdefault("contact_margin", 0.02); kw.setdefault("dt", DT)
+    return PihVecEnv(n, task_id=1, **kw)
+
+
+def test_fly_reset_and_state_roundtrip(torch_mod, oracle_mod):
+    torch = torch_mod
+    n = 70                                   # two waves, ragged
+    g = _gpu(n, seed=3); o = oracle_mod.FlyOracle(n, seed=3, dt=DT)
+    sg = g.state().cpu().numpy()
+    assert sg.shape == (n, 48)
+    np.testing.assert_allclose(sg, o.get_state(), atol=2e-6)
+    assert g.obs.shape == (n, 6)
+    np.testing.assert_allclose(g.ee_position().cpu().numpy(), sg[:, 40:43], atol=0)
+    s2 = torch.tensor(sg) + 0.0; s2[:, 18] += 0.25
+    g.set_state(s2)
+    assert torch.equal(g.state().cpu(), s2)                        # env-major <-> structure-of-arrays transposition is exact
+    mask = torch.zeros(n, dtype=torch.uint8); mask[::4] = 1
+    g.reset(mask)
+    s3 = g.state().cpu()
+    assert torch.equal(s3[mask == 0], s2[mask == 0]) and (s3[mask == 1][:, 33] > s2[mask == 1][:, 33]).all()
+    g.reset(hard_reset=True)
+    np.testing.assert_array_equal(g.state().cpu().numpy(), sg)   # hard reset replays the seed's first scene bit for bit
+
+
+@pytest.mark.parametrize("N,steps", [(4096, 200), (70, 400)])
+def test_fly_one_step_parity_resynchronised(torch_mod, oracle_mod, N, steps):
+    """Random-action episodes with auto-reset (throws, arm swings, arm-object and object-table contacts, landings, catches), the GPU
+    state overwritten with the oracle's before every step.  done / reward / contact counts must be equal; state error percentiles
+    asserted; the number of contact env-steps the run covered is asserted."""
+    torch = torch_mod
+    kw = dict(seed=7, dt=DT, residual_threshold=0.0, auto_reset=1, max_episode_steps=150)
+    o = oracle_mod.FlyOracle(N, omp=N > 256, **kw); g = _gpu(N, debug=1 if N <= 256 else 0, **kw)
+    rng = np.random.default_rng(0)
+    perr, verr, ferr = [], [], []; ncs = 0; nrew = 0; mism = 0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (N, 6))
+        g.set_state(torch.tensor(o.get_state(), dtype=torch.float32))
+        oo, ro, do = o.step(a)
+        og, rg, dg = g.step(torch.tensor(a, dtype=torch.float32))
+        so = o.get_state(); sg = g.state().cpu().numpy().astype(np.float64)
+        # an env whose object passes within float rounding of a contact / catch / landing threshold may flip one step apart
+        same = (do == dg.cpu().numpy()) & (so[:, 44] == sg[:, 44]) & (ro == rg.cpu().numpy())
+        mism += int((~same).sum())
+        ncs += int(so[:, 44].sum()); nrew += int(ro.sum())
+        perr.append(np.abs(so[same][:, [*range(0, 6), *range(18, 25)]] - sg[same][:, [*range(0, 6), *range(18, 25)]]).max(1))
+        verr.append(np.abs(so[same][:, [*range(6, 12), *range(25, 31)]] - sg[same][:, [*range(6, 12), *range(25, 31)]]).max(1))
+        ferr.append(np.abs(so[same][:, 43] - sg[same][:, 43]) / (1 + np.abs(so[same][:, 43])))
+        np.testing.assert_allclose(og.cpu().numpy()[same], oo[same], atol=2e-4)
+    perr = np.concatenate(perr); verr = np.concatenate(verr); ferr = np.concatenate(ferr)
+    print("fly N=%d: %d env-steps, %d with contacts, %d catches, %d threshold flips; pose err p50/p99/max %.2e / %.2e / %.2e ; velocity err p50/p99/max %.2e / %.2e / %.2e ; force rel err p99 %.2e" % (
+        N, N * steps, ncs, nrew, mism, np.percentile(perr, 50), np.percentile(perr, 99), perr.max(), np.percentile(verr, 50), np.percentile(verr, 99), verr.max(), np.percentile(ferr, 99)))
+    assert ncs > (20000 if N > 256 else 500) and mism <= 2e-5 * N * steps + 2
+    assert np.percentile(perr, 50) < 2e-6 and np.percentile(perr, 99) < 2e-5 and perr.max() < 1e-3
+    assert np.percentile(verr, 50) < 1e-4 and np.percentile(verr, 99) < 5e-3
+    assert np.percentile(ferr, 99) < 1e-2
+
+
+def test_fly_free_flight_trajectory_and_arm_tracking(torch_mod, oracle_mod):
+    """Trajectory parity without resynchronisation over 300 steps where the dynamics are smooth: object in damped free flight far from
+    the arm (closed form) while the arm tracks a slow circular end-effector target; peg... object pose and ee within 1e-3 m."""
+    torch = torch_mod
+    O = oracle_mod
+    N = 64
+    kw = dict(seed=2, dt=DT, residual_threshold=0.0, auto_reset=0, max_episode_steps=100000)
+    o = O.FlyOracle(N, **kw); g = _gpu(N, **kw)
+    s = o.get_state()
+    s[:, O.F_OPOS:O.F_OPOS + 3] = [3.0, 3.0, 40.0]; s[:, O.F_OVLIN:O.F_OVLIN + 3] = [1.0, -2.0, 3.0]; s[:, O.F_OVANG:O.F_OVANG + 3] = [0.5, 1.0, -2.0]
+    o.set_state(s); g.set_state(torch.tensor(s, dtype=torch.float32))
+    rest = np.array([0, -np.pi / 2, np.pi / 2, -np.pi / 2, -np.pi / 2, 0])
+    ee0, qe = O.fk_ur5(rest, 6); eul = O.euler_from_quat(qe)
+    p = np.array([3.0, 3.0, 40.0]); v = np.array([1.0, -2.0, 3.0])
+    md = 0.0
+    for t in range(300):
+        ph = 2 * np.pi * t / 300
+        a = np.tile(np.r_[ee0 + 0.08 * np.array([np.sin(ph), np.cos(ph) - 1, 0.5 * np.sin(2 * ph)]), eul], (N, 1))
+        oo, _, _ = o.step(a); og, _, _ = g.step(torch.tensor(a, dtype=torch.float32))
+        v = v + DT * (np.array([0, 0, -9.8]) - 0.04 * (1 + np.linalg.norm(v)) * v); p = p + DT * v
+        md = max(md, np.abs(oo - og.cpu().numpy()).max())
+    sg = g.state().cpu().numpy()
+    print("fly trajectory parity: obs max diff %.2e over 300 steps" % md)
+    assert md < 1e-3
+    np.testing.assert_allclose(sg[:, 18:21], np.tile(p, (N, 1)), atol=2e-3)        # closed-form damped flight (fp32 accumulation over 300 steps at z ~ 40)
+    np.testing.assert_allclose(sg[:, 25:28], np.tile(v, (N, 1)), atol=2e-4)
+
+
+def test_fly_full_size_properties(torch_mod):
+    """BASELINE configs[4] size (4096 envs, random actions, auto-reset): finite state, unit quaternions, joints inside their limits,
+    episodes end (landing / catch) and restart, bitwise run-to-run determinism, results independent of the batch size."""
+    torch = torch_mod
+    N = 4096
+    outs = []
+    for rep in range(2):
+        g = _gpu(N, auto_reset=1, seed=11)
+        gen = torch.Generator(device="cuda").manual_seed(1234)
+        ndone = 0
+        for t in range(300):
+            a = torch.rand(N, 6, device="cuda", generator=gen) * 2 - 1
+            obs, rew, done = g.step(a)
+            ndone += int(done.sum())
+        st = g.state()
+        outs.append(st.clone())
+        assert torch.isfinite(st).all() and torch.isfinite(obs).all()
+        assert torch.allclose(st[:, 21:25].norm(dim=1), torch.ones(N, device="cuda"), atol=1e-4)
+        assert (st[:, 0:6].abs() <= 3.14159265359 + 0.05).all()
+        assert ndone > 2 * N and st[:, 38].sum().item() == 0          # every env finished > 2 episodes; no non-finite resets
+        assert (st[:, 32] < 300).all()
+    assert torch.equal(outs[0], outs[1])
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    acts = torch.rand(40, 130, 6, device="cuda", generator=gen) * 2 - 1
+    a = _gpu(130, seed=3, auto_reset=1); b = _gpu(37, seed=3, auto_reset=1)
+    for t in range(40):
+        oa, _, da = a.step(acts[t]); ob, _, db = b.step(acts[t, :37].contiguous())
+        assert torch.equal(oa[:37], ob) and torch.equal(da[:37], db)
+    assert torch.equal(a.state()[:37], b.state())
+
+
+def test_fly_facade_readme_usage_on_gpu(torch_mod):
+    """README.md:38 of the reference, unchanged but for the import and client=None."""
+    import peg_in_hole_gym_amd as peg_in_hole_gym
+    env = peg_in_hole_gym.make('peg-in-hole-mp-v0', client=None, task='random-fly', mp_num=4, sub_num=4, offset=[2., 3., 0.],
+                               args=['Banana', 1 / 120.], is_test=True)
+    obs = env.reset()
+    assert len(obs) == 4 and obs[0][0].shape == (6,)
+    for _ in range(5):
+        obs, reward, done, info = env.step(env.action_space.sample())
+    assert np.isfinite(np.asarray(obs)).all() and len(done[3]) == 4
+    assert abs(env._backend.cfg.dt - 1 / 120.) < 1e-9 and env._backend.task_id == 1
+    env.close()
+    from peg_in_hole_gym_amd.envs.peg_in_hole import RandomFly
+    t = RandomFly(client=None, offset=[0, 0, 0], args=['Banana', 1 / 120.])
+    t.reset(hard_reset=True); t.apply_action(np.zeros(6, dtype=np.float32))
+    ob, r, d, inf = t.get_info()
+    assert ob.shape == (6,) and np.isfinite(ob).all()
+    t.close()

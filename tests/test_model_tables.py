@@ -81,3 +81,36 @@ def test_link_tree_shape_assumed_by_the_lane_parallel_sweeps():
     assert len(jt) == 33 and len(par) == 33
     assert jt[:7] == [REV] * 7 and jt[7:9] == [PRI] * 2 and jt[9] == FLO and jt[10:] == [REV] * 23
     assert par[:9] == [-1, 0, 1, 2, 3, 4, 5, 6, 6] and par[9] == -1 and par[10:] == list(range(9, 32))
+
+
+def test_header_regenerates_byte_identical_from_the_reference_assets():
+    """tools/gen_model_header.py READS pipe.urdf, hole's OBJ, ur5.urdf + its STL collision meshes and banana.urdf + its hull
+    OBJ from the reference tree (only the Panda / table block is hand-entered, their assets live in the absent pybullet_data):
+    regenerating must reproduce the committed include/pih_model.h byte for byte."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_model_header.py"), "--ref", REF], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout == open(os.path.join(ROOT, "include", "pih_model.h")).read()
+
+
+def test_ur5_dynamics_and_banana_tables_match_the_files(T):
+    u = T.ur5_tables(REF)
+    np.testing.assert_allclose(_macro("PIH_UR5_MASS")[:5], u["mass"][:5], atol=0)
+    assert abs(_macro("PIH_UR5_MASS")[5] - (u["mass"][5] + u["ee_mass"])) < 1e-15          # wrist_3_link + ee_link (fixed joint)
+    np.testing.assert_allclose(_macro("PIH_UR5_COM")[:5], u["com"][:5], atol=0)
+    np.testing.assert_allclose(_macro("PIH_UR5_DAMPING"), u["damping"], atol=0)
+    np.testing.assert_allclose(_macro("PIH_UR5_LO"), u["lower"], atol=0); np.testing.assert_allclose(_macro("PIH_UR5_HI"), u["upper"], atol=0)
+    # box-inertia rule on the STL AABB (+ 1 mm margin each side) for a link without a merged child
+    lo, hi = np.array(u["aabb"][1][0]), np.array(u["aabb"][1][1])
+    np.testing.assert_allclose(_macro("PIH_UR5_INERTIA")[1][:3], T.box_inertia_diag(u["mass"][1], (hi - lo) + 0.002), rtol=1e-12)
+    # capsules stay inside the link's AABB
+    A, B, R = _macro("PIH_UR5_CAP_A"), _macro("PIH_UR5_CAP_B"), _macro("PIH_UR5_CAP_R")
+    for k in range(6):
+        lo, hi = np.array(u["aabb"][k][0]), np.array(u["aabb"][k][1])
+        ax = int(np.argmax(hi - lo))
+        assert A[k][ax] - R[k] >= lo[ax] - 1e-6 and B[k][ax] + R[k] <= hi[ax] + 1e-6
+    b = T.banana_tables(REF)
+    assert _macro("PIH_FLY_OBJ_MASS") == b["mass"] == 1.0 and _macro("PIH_FLY_OBJ_MU") == b["friction"] == 0.0
+    assert int(_macro("PIH_FLY_OBJ_NSPH")) == len(b["hull_aabb"]) == 5
+    ext = np.array(b["aabb"][1]) - np.array(b["aabb"][0]) + 0.002
+    np.testing.assert_allclose(_macro("PIH_FLY_OBJ_INERTIA"), T.box_inertia_diag(1.0, ext), rtol=1e-9)

@@ -12,12 +12,34 @@ Sources (reference paths relative to /root/reference/peg_in_hole_gym/):
             (envs/peg_in_hole.py:235, envs/utils.py:24-28).
   * ur5   : envs/assets/urdf/ur5.urdf:32-218,534-539 (exact).
 
+  * banana: envs/assets/urdf/banana.urdf:1-32 + obj/banana_collision.obj (5 convex hulls) -- the free-flying object of
+            the 'random-fly' task (README.md:38).
+
+Everything that exists in the reference tree is READ from it (tools/urdf_tables.py: URDF via xml.etree, fixed-joint merge,
+globalScaling, OBJ / binary-STL collision meshes for the AABB box-inertia rule); only the Panda and the table, whose assets
+live in the absent pybullet_data package, are a hand-entered block (marked PROVISIONAL).  tests/test_model_tables.py
+regenerates the header where /root/reference exists and requires it to be byte-identical to the committed one.
+
 The header is plain C initialiser macros so that both the fp64 oracle (oracle/) and the HIP
 product (peg_in_hole_gym_amd/csrc) instantiate the same numbers in their own storage classes.
-Run:  python tools/gen_model_header.py > include/pih_model.h
+Run:  python tools/gen_model_header.py [--ref /root/reference] > include/pih_model.h
 """
 import math
+import os
+import sys
+
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import urdf_tables as UT  # noqa: E402
+
+REF = sys.argv[sys.argv.index("--ref") + 1] if "--ref" in sys.argv else "/root/reference"
+PIPE = UT.pipe_tables(REF)
+HOLE = UT.hole_tables(REF)
+UR5 = UT.ur5_tables(REF)
+BANANA = UT.banana_tables(REF)
+MARGIN = 0.001          # pybullet's default collision margin for URDF meshes [UNVERIFIED, SURVEY.md App. C]
+DEFAULT_MU = 0.5        # pybullet's default lateral friction for links without a <contact> block
 
 np.set_printoptions(precision=17)
 
@@ -69,7 +91,9 @@ def sym6(I):
 
 
 def fmt(x):
-    return repr(float(x))
+    x = float(x)
+    r = round(x, 12)
+    return repr((r if abs(r - x) < 4e-16 else x) + 0.0)     # parsed-and-scaled decimals such as 3 * 0.01 + 5.5 * 0.01 print as 0.085
 
 
 def arr(xs):
@@ -117,35 +141,42 @@ EE_PARENT = 6
 EE_R = snap(Rh)
 EE_T = (0, 0, 0.107 + 0.105)
 
-# ----------------------------------------------------------------------------- pipe (object links 0..23)
-S = 0.01  # globalScaling envs/peg_in_hole.py:242
+# ----------------------------------------------------------------------------- pipe (object links 0..23), READ from pipe.urdf
+S = 0.01  # globalScaling envs/peg_in_hole.py:242 (already applied by urdf_tables.pipe_tables)
 # PyBullet (no URDF_USE_INERTIA_FROM_FILE) recomputes link inertia from the collision AABB [UNVERIFIED,
-# SURVEY.md App. C]: cylinder r=1,len 6 scaled + 1 mm margin -> box 0.022 x 0.062 x 0.022
-pipe_box = lambda m: box_inertia(m, 0.022, 0.062, 0.022)
-# root = pipe_link0 (m .00111, com at origin, pipe.urdf:13-19) + pipe_link1 (fixed at y=3, m .0111,
-# inertial origin y=1.5, pipe.urdf:39-43,:52-56)
-m0, c0, I0 = merge([(0.00111, (0, 0, 0), pipe_box(0.00111)), (0.0111, (0, (3 + 1.5) * S, 0), pipe_box(0.0111))])
-add("pipe_link0+1", -1, FLT, np.eye(3), (0, 0, 0), (0, 0, 0), m0, c0, I0, 0, 0, 0, 0.0, 100.0)
-for k in range(2, 25):  # pipe_link2..24 ; joint index k-1 (pipe.urdf:76-83 ... :791-798)
+# SURVEY.md App. C]: cylinder r=1, len 6 scaled + 1 mm margin -> box 0.022 x 0.062 x 0.022
+pipe_ext = PIPE["aabb_ext"]
+pipe_box = lambda m: box_inertia(m, *pipe_ext)
+mu_of = lambda f: DEFAULT_MU if f is None else f
+jx = PIPE["joint_xyz"]              # 24 joints: [0] fixed link0->link1, [1..23] continuous
+# root = pipe_link0 + pipe_link1 (fixed joint): one rigid link
+m0, c0, I0 = merge([(PIPE["mass"][0], PIPE["com"][0], pipe_box(PIPE["mass"][0])),
+                    (PIPE["mass"][1], np.array(jx[0]) + np.array(PIPE["com"][1]), pipe_box(PIPE["mass"][1]))])
+add("pipe_link0+1", -1, FLT, np.eye(3), (0, 0, 0), (0, 0, 0), m0, c0, I0, 0, 0, 0, 0.0, max(mu_of(PIPE["friction"][0]), mu_of(PIPE["friction"][1])))
+for k in range(2, 25):  # pipe_link2..24 ; URDF joint index k-1
     j = k - 1  # object link index
-    ty = (3 + 5.5) * S if k == 2 else 5.5 * S  # link2's joint sits on link1 (y=5.5) which sits at y=3 of link0
-    axis = (0, 0, 1) if k % 2 == 0 else (1, 0, 0)  # alternating z,x (pipe.urdf:81,114,...)
-    com = (0, 1.5 * S, 0) if k == 24 else (0, 0, 0)  # inertial origin only on link1 & link24 (pipe.urdf:53,807)
-    mu = 100.0 if k >= 23 else 0.5  # lateral_friction 100 on links 0,1,23,24 (pipe.urdf:10,48,765,802)
-    add("pipe_link%d" % k, ARM_NL + j - 1, REV, np.eye(3), (0, ty, 0), axis, 0.0111, com, pipe_box(0.0111), 0, 0, 0, 0.0, mu)
+    t = np.array(jx[k - 1]) + (np.array(jx[0]) if k == 2 else 0)   # link2's joint sits on link1, which sits on link0 at jx[0]
+    add("pipe_link%d" % k, ARM_NL + j - 1, REV, np.eye(3), t, PIPE["joint_axis"][k - 1], PIPE["mass"][k], PIPE["com"][k],
+        pipe_box(PIPE["mass"][k]), 0, 0, 0, 0.0, mu_of(PIPE["friction"][k]))
 NL = len(links)
 OBJ_NL = NL - ARM_NL
 
-# collision rope: vertices V0..V24 (sphere r = 1 cm) ; segment s on object link s from V_s to V_{s+1}
-PIPE_R = 1.0 * S
+# collision rope: vertices V0..V24 (sphere r = 1 cm) ; segment s on object link s from V_s to V_{s+1}.  The mesh cylinder of
+# every link (collision origin y = 0.03, half length 0.03, radius 0.01 -- from the OBJ's AABB) starts at the link origin.
+PIPE_R = 0.5 * (pipe_ext[0] - 2 * MARGIN)
+cyl_half = 0.5 * (pipe_ext[1] - 2 * MARGIN)
+col_y = PIPE["collision_xyz"][0][1]
+y_first = col_y - cyl_half + PIPE_R                      # first vertex: one radius inside the first cylinder's start
+y_last = col_y + cyl_half - PIPE_R                       # last vertex: one radius inside the last cylinder's end
+step_y = jx[1][1]                                        # joint spacing along the chain
 samples = []  # (obj_link, local_y, is_vertex)
-seg_len = [8.5 * S - 1.0 * S] + [5.5 * S] * 22 + [5.0 * S]
-seg_y0 = [1.0 * S] + [0.0] * 23
-for s in range(24):
-    n_int = 6 if s == 0 else 4
-    samples.append((s, seg_y0[s], 1))
-    for i in range(1, n_int + 1):
-        samples.append((s, seg_y0[s] + seg_len[s] * i / (n_int + 1), 0))
+seg_len = [jx[0][1] + step_y - y_first] + [step_y] * 22 + [y_last]
+seg_y0 = [y_first] + [0.0] * 23
+for s_ in range(24):
+    n_int = 6 if s_ == 0 else 4
+    samples.append((s_, seg_y0[s_], 1))
+    for i_ in range(1, n_int + 1):
+        samples.append((s_, seg_y0[s_] + seg_len[s_] * i_ / (n_int + 1), 0))
 samples.append((23, seg_y0[23] + seg_len[23], 1))
 
 print("/* GENERATED by tools/gen_model_header.py -- do not edit.  DATA ONLY (model constants).")
@@ -202,9 +233,9 @@ print("/* static geometry (env-local frame) */")
 print("#define PIH_TABLE_Z (-0.05)   /* SURVEY.md App. A [UNVERIFIED]: -1.3 + 2*0.625 */")
 print("#define PIH_TABLE_MU 1.0")
 print("#define PIH_HOLE_POS {0.5, -0.2, 0.2}   /* envs/peg_in_hole.py:248 */")
-print("#define PIH_HOLE_HALFLEN %s  /* 1.0 * 0.016 */" % fmt(0.016))
-print("#define PIH_HOLE_RIN %s   /* 0.96 * 0.016 */" % fmt(0.96 * 0.016))
-print("#define PIH_HOLE_ROUT %s  /* 1.2 * 0.016 */" % fmt(1.2 * 0.016))
+print("#define PIH_HOLE_HALFLEN %s  /* cylinder_base.obj half height x globalScaling 0.016 (envs/peg_in_hole.py:251) */" % fmt(round(HOLE["halflen"], 7)))
+print("#define PIH_HOLE_RIN %s   /* inner radius x 0.016 */" % fmt(round(HOLE["rin"], 7)))
+print("#define PIH_HOLE_ROUT %s  /* outer radius x 0.016 */" % fmt(round(HOLE["rout"], 7)))
 print("#define PIH_HOLE_MU 0.5")
 print("#define PIH_GRAVITY_Z (-9.8)  /* envs/peg_in_hole.py:230 */")
 # scripted FSM clock (envs/peg_in_hole.py:206-212,254,263): number of update_state() calls spent in each state before the
@@ -220,23 +251,69 @@ for dur in durs:
             break
     fsm_steps.append(k)
 print("#define PIH_FSM_STEPS " + iarr(fsm_steps) + "  /* update_state() calls per FSM state (exact replay of the fp64 clock) */")
-# ----------------------------------------------------------------------------- UR5 (envs/assets/urdf/ur5.urdf, exact)
-ur = [  # (rpy, xyz, axis)  shoulder_pan :32-38, shoulder_lift :60-66, elbow :88-94, wrist_1 :116-122, wrist_2 :145-151, wrist_3 :173-179
-    ((0.0, 0.0, 3.14), (0.0, 0.0, 0.089159), (0, 0, 1)),
-    ((0.0, 1.6, 0.0), (0.0, 0.13585, 0.0), (0, 1, 0)),
-    ((0.0, 0.0, 0.0), (0.0, -0.1197, 0.425), (0, 1, 0)),
-    ((0.0, 1.57079632679, 0.0), (0.0, 0.0, 0.39225), (0, 1, 0)),
-    ((0.0, 0.0, 0.0), (0.0, 0.093, 0.0), (0, 0, 1)),
-    ((0.0, 0.0, 0.0), (0.0, 0.0, 0.09465), (0, 1, 0)),
-]
+# ----------------------------------------------------------------------------- UR5 (envs/assets/urdf/ur5.urdf, READ from the file)
+ur = list(zip(UR5["rpy"], UR5["xyz"], UR5["axis"]))   # shoulder_pan :32-38, shoulder_lift :60-66, elbow :88-94, wrist_1 :116-122, wrist_2 :145-151, wrist_3 :173-179
 print("/* UR5 kinematic chain (ur5.urdf:32-218; world->base fixed xyz 0 0 0.1 :534-539; ee_fixed_joint :201-205), literal 3.14 / 1.6 */")
 print("#define PIH_UR5_NJ 6")
 print("#define PIH_UR5_RFIX {" + ", ".join(arr(rpy(*j[0]).reshape(-1)) for j in ur) + "}")
 print("#define PIH_UR5_TFIX {" + ", ".join(arr(j[1]) for j in ur) + "}")
 print("#define PIH_UR5_AXIS {" + ", ".join(arr(j[2]) for j in ur) + "}")
-print("#define PIH_UR5_BASE_T {0.0, 0.0, 0.1}")
-print("#define PIH_UR5_EE_R " + arr(rpy(0.0, 0.0, 1.57079632679).reshape(-1)))
-print("#define PIH_UR5_EE_T {0.0, 0.0823, 0.0}")
-print("#define PIH_UR5_EFFORT {300.0, 300.0, 300.0, 300.0, 300.0, 300.0}   /* getJointInfo(i)[10], envs/utils.py:75-78 */")
+print("#define PIH_UR5_BASE_T " + arr(UR5["base_xyz"]))
+print("#define PIH_UR5_EE_R " + arr(rpy(*UR5["ee_rpy"]).reshape(-1)))
+print("#define PIH_UR5_EE_T " + arr(UR5["ee_xyz"]))
+print("#define PIH_UR5_EFFORT " + arr(UR5["effort"]) + "   /* getJointInfo(i)[10], envs/utils.py:75-78 */")
 print("#define PIH_UR5_KP 0.03   /* positionGains, envs/utils.py:82 */")
+# ---- UR5 dynamics for the 'random-fly' task: masses / inertial origins / joint damping / limits from the URDF; inertia by
+# pybullet's rule without URDF_USE_INERTIA_FROM_FILE (box of the collision-mesh AABB + margin, about the inertial origin, link
+# axes) [UNVERIFIED rule, SURVEY.md App. C]; ee_link (fixed, 1 kg, 1 cm box :206-217) merged into wrist_3_link
+ur_m, ur_c, ur_I = [], [], []
+for k in range(6):
+    lo, hi = np.array(UR5["aabb"][k][0]), np.array(UR5["aabb"][k][1])
+    parts = [(UR5["mass"][k], UR5["com"][k], box_inertia(UR5["mass"][k], *((hi - lo) + 2 * MARGIN)))]
+    if k == 5:
+        elo, ehi = np.array(UR5["ee_aabb"][0]), np.array(UR5["ee_aabb"][1])
+        Re = rpy(*UR5["ee_rpy"])
+        parts.append((UR5["ee_mass"], np.array(UR5["ee_xyz"]) + Re @ np.array(UR5["ee_com"]), Re @ box_inertia(UR5["ee_mass"], *((ehi - elo) + 2 * MARGIN)) @ Re.T))
+    m_, c_, I_ = merge(parts)
+    ur_m.append(m_); ur_c.append(c_); ur_I.append(I_)
+print("/* UR5 dynamics (random-fly task): link k = child of joint k; link 5 = wrist_3_link + ee_link merged */")
+print("#define PIH_UR5_MASS " + arr(ur_m))
+print("#define PIH_UR5_COM {" + ", ".join(arr(c) for c in ur_c) + "}")
+print("#define PIH_UR5_INERTIA {" + ", ".join(arr(sym6(I)) for I in ur_I) + "}  /* xx yy zz xy xz yz about COM, link axes */")
+print("#define PIH_UR5_DAMPING " + arr(UR5["damping"]) + "  /* <dynamics damping>, ur5.urdf:38,66,94,122,151,179 */")
+print("#define PIH_UR5_LO " + arr(UR5["lower"]))
+print("#define PIH_UR5_HI " + arr(UR5["upper"]))
+print("#define PIH_UR5_MU %s" % fmt(DEFAULT_MU))
+# collision capsules of the arm links, one per link, by a fixed rule from the collision-mesh AABB (BUILD-DEFINED stand-in for the
+# STL convex hulls): axis = longest AABB axis through the AABB centre, radius = mean of the other two half extents, end points
+# one radius inside the AABB (a sphere when the box is shorter than two radii)
+caps = []
+for k in range(6):
+    lo, hi = np.array(UR5["aabb"][k][0]), np.array(UR5["aabb"][k][1])
+    c, h = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    ax = int(np.argmax(h))
+    r = float(np.mean([h[i_] for i_ in range(3) if i_ != ax]))
+    half = max(float(h[ax]) - r, 0.0)
+    e = np.zeros(3); e[ax] = half
+    caps.append((c - e, c + e, r))
+print("#define PIH_UR5_CAP_A {" + ", ".join(arr(np.round(c[0], 9)) for c in caps) + "}   /* capsule end points / radius in the link frame */")
+print("#define PIH_UR5_CAP_B {" + ", ".join(arr(np.round(c[1], 9)) for c in caps) + "}")
+print("#define PIH_UR5_CAP_R " + arr(round(c[2], 9) for c in caps))
+print("#define PIH_UR5_REST {0.0, %s, %s, %s, %s, 0.0}   /* BUILD-DEFINED rest pose (the reference passes ur_orn from a task that is not in the snapshot) */" % (
+    fmt(-math.pi / 2), fmt(math.pi / 2), fmt(-math.pi / 2), fmt(-math.pi / 2)))
+# ----------------------------------------------------------------------------- banana (envs/assets/urdf/banana.urdf + obj/banana_collision.obj)
+blo, bhi = np.array(BANANA["aabb"][0]), np.array(BANANA["aabb"][1])
+bI = box_inertia(BANANA["mass"], *((bhi - blo) + 2 * MARGIN))
+print("/* free-flying object of the random-fly task: banana.urdf:1-32 (1 kg, lateral_friction 0, contact_erp 0), inertia = AABB box of")
+print(" * banana_collision.obj; collision = one sphere per convex hull of that file (centre = hull AABB centre, radius = mean half extent:")
+print(" * BUILD-DEFINED stand-in for the 5 hulls with %s vertices) */" % "/".join(str(n) for n in BANANA["hull_nvert"]))
+print("#define PIH_FLY_OBJ_MASS %s" % fmt(BANANA["mass"]))
+print("#define PIH_FLY_OBJ_INERTIA " + arr(np.diag(bI)) + "   /* xx yy zz about the inertial origin (banana.urdf:12), body axes */")
+print("#define PIH_FLY_OBJ_MU %s" % fmt(BANANA["friction"]))
+print("#define PIH_FLY_OBJ_NSPH %d" % len(BANANA["hull_aabb"]))
+hc = [0.5 * (np.array(a) + np.array(b)) for a, b in BANANA["hull_aabb"]]
+hr = [float(np.mean(0.5 * (np.array(b) - np.array(a)))) for a, b in BANANA["hull_aabb"]]
+print("#define PIH_FLY_OBJ_SPH_C {" + ", ".join(arr(np.round(c, 9)) for c in hc) + "}")
+print("#define PIH_FLY_OBJ_SPH_R " + arr(round(r, 9) for r in hr))
+print("#define PIH_FLY_OBJ_RGB " + arr(BANANA["rgba"][:3]) + "   /* <material> colour, banana.urdf:21-23 */")
 print("#endif")

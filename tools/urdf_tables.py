@@ -37,6 +37,32 @@ def obj_vertices(path):
     return np.array(v)
 
 
+def stl_vertices(path):
+    """Vertices of a binary STL (80-byte header, uint32 triangle count, 50 bytes per triangle)."""
+    import struct
+    b = open(path, "rb").read()
+    n = struct.unpack("<I", b[80:84])[0]
+    assert len(b) == 84 + 50 * n, "not a binary STL: %s" % path
+    a = np.frombuffer(b[84:], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+    return a["v"].reshape(-1, 3).astype(np.float64)
+
+
+def obj_hulls(path):
+    """Vertex arrays of the `o <name>` groups of an OBJ (banana_collision.obj: one convex hull per group)."""
+    hulls, cur = [], None
+    with open(path) as f:
+        for line in f:
+            if line.startswith("o "):
+                cur = []; hulls.append(cur)
+            elif line.startswith("v ") and cur is not None:
+                cur.append([float(x) for x in line.split()[1:4]])
+    return [np.array(h) for h in hulls]
+
+
+def mesh_vertices(path):
+    return stl_vertices(path) if path.lower().endswith(".stl") else obj_vertices(path)
+
+
 class Urdf:
     def __init__(self, path, scale=1.0):
         self.path = path
@@ -44,7 +70,10 @@ class Urdf:
         root = ET.parse(path).getroot()
         self.links = {}
         for l in root.findall("link"):
-            d = {"name": l.get("name"), "mass": 0.0, "com": [0, 0, 0], "friction": None, "collision": None}
+            d = {"name": l.get("name"), "mass": 0.0, "com": [0, 0, 0], "friction": None, "collision": None, "rgba": None}
+            vis = l.find("visual")
+            if vis is not None and vis.find("material") is not None and vis.find("material").find("color") is not None:
+                d["rgba"] = _floats(vis.find("material").find("color").get("rgba"), 4)
             ine = l.find("inertial")
             if ine is not None:
                 m = ine.find("mass")
@@ -59,8 +88,10 @@ class Urdf:
             if col is not None:
                 o = col.find("origin")
                 mesh = col.find("geometry").find("mesh") if col.find("geometry") is not None else None
+                box = col.find("geometry").find("box") if col.find("geometry") is not None else None
                 d["collision"] = {"xyz": [x * scale for x in _floats(o.get("xyz") if o is not None else None)],
-                                  "mesh": mesh.get("filename") if mesh is not None else None}
+                                  "mesh": mesh.get("filename") if mesh is not None else None,
+                                  "box": [x * scale for x in _floats(box.get("size"))] if box is not None else None}
             self.links[d["name"]] = d
         self.joints = []
         for j in root.findall("joint"):
@@ -79,10 +110,18 @@ class Urdf:
 
     def mesh_aabb_extents(self, link, margin=0.001):
         """Scaled AABB extents (+ 2 * collision margin) of the link's collision mesh."""
+        lo, hi = self.mesh_aabb(link)
+        return (hi - lo) + 2 * margin
+
+    def mesh_aabb(self, link):
+        """Scaled AABB (min, max) of the link's collision geometry in the link frame (mesh file or <box>)."""
         c = self.links[link]["collision"]
+        if c["box"] is not None:
+            h = 0.5 * np.array(c["box"]); o = np.array(c["xyz"])
+            return o - h, o + h
         p = os.path.normpath(os.path.join(os.path.dirname(self.path), c["mesh"]))
-        v = obj_vertices(p) * self.scale
-        return (v.max(0) - v.min(0)) + 2 * margin
+        v = mesh_vertices(p) * self.scale + np.array(c["xyz"])
+        return v.min(0), v.max(0)
 
     def chain(self, root_link):
         """Joints in order down a serial chain starting at root_link."""
@@ -123,13 +162,29 @@ def ur5_tables(ref_root):
     ch = u.chain("world")
     rev = [j for j in ch if j["type"] == "revolute"]
     fixed = [j for j in ch if j["type"] == "fixed"]
+    links = [j["child"] for j in rev]
+    ee = fixed[-1]["child"]
     return {"base_xyz": fixed[0]["xyz"], "rpy": [j["rpy"] for j in rev], "xyz": [j["xyz"] for j in rev], "axis": [j["axis"] for j in rev],
             "effort": [j["effort"] for j in rev], "damping": [j["damping"] for j in rev], "ee_rpy": fixed[-1]["rpy"], "ee_xyz": fixed[-1]["xyz"],
-            "mass": [u.links[j["child"]]["mass"] for j in rev]}
+            "lower": [float(j["lower"]) for j in rev], "upper": [float(j["upper"]) for j in rev],
+            "mass": [u.links[l]["mass"] for l in links], "com": [u.links[l]["com"] for l in links],
+            "aabb": [[a.tolist() for a in u.mesh_aabb(l)] for l in links],
+            "ee_mass": u.links[ee]["mass"], "ee_com": u.links[ee]["com"], "ee_aabb": [a.tolist() for a in u.mesh_aabb(ee)]}
+
+
+def banana_tables(ref_root):
+    """envs/assets/urdf/banana.urdf:1-32 + obj/banana_collision.obj (one convex hull per `o` group)."""
+    u = Urdf(os.path.join(ref_root, "peg_in_hole_gym/envs/assets/urdf/banana.urdf"))
+    l = u.links["banana"]
+    hulls = obj_hulls(os.path.normpath(os.path.join(os.path.dirname(u.path), l["collision"]["mesh"])))
+    allv = np.concatenate(hulls)
+    return {"mass": l["mass"], "com": l["com"], "friction": l["friction"], "rgba": l["rgba"],
+            "aabb": [allv.min(0).tolist(), allv.max(0).tolist()],
+            "hull_aabb": [[h.min(0).tolist(), h.max(0).tolist()] for h in hulls], "hull_nvert": [len(h) for h in hulls]}
 
 
 if __name__ == "__main__":
     import json
     import sys
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
-    print(json.dumps({"pipe": pipe_tables(ref), "hole": hole_tables(ref), "ur5": ur5_tables(ref)}, indent=1)[:3000])
+    print(json.dumps({"pipe": pipe_tables(ref), "hole": hole_tables(ref), "ur5": ur5_tables(ref), "banana": banana_tables(ref)}, indent=1)[:6000])
