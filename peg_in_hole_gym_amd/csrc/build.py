@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "pih_hip.hip")
 OUT = os.path.join(HERE, "libpih_hip.so")
-DEPS = [SRC, os.path.join(HERE, "pih_device.h"), os.path.join(HERE, "pih_render.h"), os.path.join(HERE, "pih_math.h"),
+DEPS = [SRC, os.path.join(HERE, "pih_device.h"), os.path.join(HERE, "pih_common.h"), os.path.join(HERE, "pih_wave.h"), os.path.join(HERE, "pih_step.h"), os.path.join(HERE, "pih_fly.h"), os.path.join(HERE, "pih_render.h"), os.path.join(HERE, "pih_math.h"),
         os.path.join(HERE, "..", "..", "include", "pih.h"), os.path.join(HERE, "..", "..", "include", "pih_model.h")]
 
 

@@ -1,0 +1,844 @@
+// pih_common.h -- model tables, per-env LDS layout and the lane-parallel phases of the per-env step that are written against
+// the wave context `W` only (w.par / w.par_all / w.alloc / w.sync): kinematics helpers, IK, reset, controller, collision
+// detection, unit-impulse responses and the constraint-row build.  The wave context itself and the phases that use wave
+// primitives directly (forward-kinematics scan, link-velocity scans, the ABA inward sweep, PGS) live in pih_wave.h -- the
+// product's gfx950 implementation.  (tests/emul supplies a host implementation of that layer so that the algorithm can be
+// checked against the fp64 oracle in a GPU-less container; nothing of it is in the product tree.)
+//
+// What replaces what (paths relative to /root/reference/peg_in_hole_gym/):
+//   fk_*            p.getLinkState                    envs/utils.py:62, envs/peg_in_hole.py:58,115,123
+//   ik_chain        p.calculateInverseKinematics      envs/utils.py:67 (BussIK DLS restated)
+//   controller      panda_execute / grasp_process     envs/utils.py:60-68 / envs/peg_in_hole.py:122-212
+//   collide, aba, build_rows, pgs, integrate   p.stepSimulation   envs/base_env.py:64, envs/peg_in_hole.py:108
+//   reset_state     PegInHole.reset                   envs/peg_in_hole.py:227-274
+//
+// Dynamics: articulated-body algorithm in world-aligned axes with each link's own origin as reference point
+// (parent<->child transforms are pure translations; classical accelerations, so the floating base comes out directly
+// in the (world linear velocity of the base origin, world angular velocity) parameterisation the state uses).
+// Constraint rows get their unit-impulse response from the same articulated inertias (one lane per row), then
+// sequential-impulse PGS runs with one lane per DOF; the Jacobian entries are recomputed on the fly from the
+// contact point/direction so only the response rows (W = M^-1 J^T) are staged in LDS.
+#pragma once
+#include "../../include/pih.h"
+#include "../../include/pih_model.h"
+#include "pih_math.h"
+
+namespace pih {
+
+constexpr int NL = PIH_NL, ANL = PIH_ARM_NL, ONL = PIH_OBJ_NL, ND = PIH_NDOF;
+constexpr int NSAMP = PIH_PIPE_NSAMP;
+constexpr int CMAX = 48;      // contacts per env
+constexpr int CAMAX = 12;     // of which may involve the arm (same cap as the oracle's PIHO_CAMAX)
+constexpr int CL = 20;        // contacts whose solver data live in LDS; contacts CL..CMAX-1 spill to a global scratch
+constexpr int NROWC = 3 * CMAX;
+constexpr int CREC = 32;      // words per packed contact record
+constexpr int WPS = 39;       // LDS row stride of a contact response row: entry d = DOF d (9 arm + 29 pipe), word 38 = 0 (read by idle lanes)
+constexpr int WMS = 31;       // row stride of the staged pipe-motor response rows (29 used)
+constexpr int NMOT = 32;      // 9 arm + 23 pipe joint motors
+constexpr int NLIM = 18;
+
+PIH_CONST int L_PARENT[NL] = PIH_LINK_PARENT;
+PIH_CONST int L_JTYPE[NL] = PIH_LINK_JTYPE;
+PIH_CONST real L_RFIX[NL][9] = PIH_LINK_RFIX;
+PIH_CONST real L_TFIX[NL][3] = PIH_LINK_TFIX;
+PIH_CONST real L_AXIS[NL][3] = PIH_LINK_AXIS;
+PIH_CONST real L_MASS[NL] = PIH_LINK_MASS;
+PIH_CONST real L_COM[NL][3] = PIH_LINK_COM;
+PIH_CONST real L_INERTIA[NL][6] = PIH_LINK_INERTIA;
+PIH_CONST real L_LO[NL] = PIH_LINK_LO;
+PIH_CONST real L_HI[NL] = PIH_LINK_HI;
+PIH_CONST real L_DAMPING[NL] = PIH_LINK_DAMPING;
+PIH_CONST real L_MU[NL] = PIH_LINK_MU;
+PIH_CONST real ARM_BASE_R[9] = PIH_ARM_BASE_R;
+PIH_CONST real EE_R[9] = PIH_EE_R;
+PIH_CONST real EE_T[3] = PIH_EE_T;
+PIH_CONST real ARM_REST[9] = PIH_ARM_REST;
+PIH_CONST real FBOX_C[2][3] = PIH_FINGER_BOX_C;
+PIH_CONST real FBOX_H[3] = PIH_FINGER_BOX_H;
+PIH_CONST int ASPH_LINK[PIH_ARM_NSPH] = PIH_ARM_SPH_LINK;
+PIH_CONST real ASPH_C[PIH_ARM_NSPH][3] = PIH_ARM_SPH_C;
+PIH_CONST real ASPH_R[PIH_ARM_NSPH] = PIH_ARM_SPH_R;
+PIH_CONST int SAMP_LINK[NSAMP] = PIH_PIPE_SAMP_LINK;
+PIH_CONST real SAMP_Y[NSAMP] = PIH_PIPE_SAMP_Y;
+PIH_CONST int SAMP_VERTEX[NSAMP] = PIH_PIPE_SAMP_VERTEX;
+PIH_CONST real HOLE_POS[3] = PIH_HOLE_POS;
+PIH_CONST real UR5_RFIX[6][9] = PIH_UR5_RFIX;
+PIH_CONST real UR5_TFIX[6][3] = PIH_UR5_TFIX;
+PIH_CONST real UR5_AXIS[6][3] = PIH_UR5_AXIS;
+PIH_CONST real UR5_BASE_T[3] = PIH_UR5_BASE_T;
+PIH_CONST real UR5_EE_R[9] = PIH_UR5_EE_R;
+PIH_CONST real UR5_EE_T[3] = PIH_UR5_EE_T;
+PIH_CONST real IDENT3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+PIH_CONST real ZERO3[3] = {0, 0, 0};
+// envs/peg_in_hole.py:206-212,263: the reference's clock `t += 1/240; if t > dur[s]` evaluated in fp64 fires after exactly
+// FSM_STEPS[s] calls; the device counts steps (fp32 accumulation of 1/240 would fire one step late in some states)
+PIH_CONST int FSM_STEPS[10] = PIH_FSM_STEPS;
+
+#define PIH_PI ((real)3.14159265358979323846)
+#define PIH_LIN_DAMP ((real)0.04)
+#define PIH_ANG_DAMP ((real)0.04)
+#define PIH_MAX_COORD_VEL ((real)100)
+#define PIH_MAX_FRICTION ((real)10)
+#define PIH_BIG ((real)1e30)
+
+// Accumulator type of the articulated-inertia sweep.  Measured (tests/emul, f32 vs f32a builds): keeping this sweep in
+// fp64 halves the fp32 error of the free acceleration (1e-5 -> 5e-6 relative) but leaves the one-step pose / contact-force
+// error percentiles unchanged (those are dominated by PGS on the mu = 10 tip contacts), so the product uses `real`.
+#ifdef PIH_AREAL
+typedef PIH_AREAL areal;
+#else
+typedef real areal;
+#endif
+
+struct Params {
+  real dt, resid, erp, warm, margin, slop, ikdamp, ikres, dv;
+  int iters, ikiters, mode, maxsteps, autoreset, selfcol, armcol, debug, env0;
+  uint64_t seed;
+};
+
+// dof index of link L: arm link i -> i ; pipe root (link 9) -> 9..14 (lin xyz, ang xyz) ; pipe link L>=10 -> L+5
+PIH_HD int link_dof(int L) { return L < ANL ? L : (L == ANL ? 9 : L + 5); }
+
+// Packed per-contact solver record (CREC = 32 words, 128-bit aligned so the PGS loop reads it with b128 broadcasts):
+//  0-2 p | 3 lower bound of the normal row (0, attach: -BIG) | 4 floor of the friction bound (0, attach: +BIG) | 5 mu | 6 - | 7 -
+//  8-10 n | 11 dinv_n | 12-14 t1 | 15 dinv_t1 | 16-18 t2 | 19 dinv_t2
+//  20-22 rhs (n,t1,t2) | 23 G[t1][n] | 24 G[t2][n] | 25 G[t2][t1] | 26-28 dvp_n, then multipliers | 29-31 dvp_t1, then sqrt(resid)*dinv
+// (dvp_k = relative velocity change at the contact point per unit impulse along direction k; G[a][b] = dir_a . dvp_b
+//  are the cross terms that make the in-block (n, t1, t2) update exact Gauss-Seidel)
+
+// LDS is time-multiplexed: the kinematics / ABA scratch (arena A) is dead once the free velocity update is done, the
+// solver scratch (arena B) is dead once the PGS result has been folded into the velocities.
+struct ArenaA {
+  real LR[NL][9], LRC[NL][3], LIC[NL][6];   // world rotation, com offset, inertia about com (world axes)
+  alignas(16) real IAP[NL][28];   // per link: own spatial inertia about the link origin (A6 B9 C6) + bias force (6) + pad
+  real CB[NL][6];                  // velocity-product accelerations, then (alpha, acc) of each link
+  real SP[NSAMP][3];               // collision sample spheres
+};
+struct ArenaB {
+  // response rows of the first CL contacts; the 32 motor response rows (Wmp 23 x WMS, then Wma 9 x 9) are staged in the
+  // same words first and pulled into registers before the contact rows overwrite them
+  real Wp[3 * CL][WPS];
+  alignas(16) real crec[CL][CREC];
+};
+constexpr int WMA_OFF = PIH_OBJ_NJ * WMS;   // word offset of Wma inside the staging block
+constexpr int WSTAGE = 3 * CL * WPS - (WMA_OFF + 81);   // the staging block sits at the END of ArenaB::Wp ...
+constexpr int MERGED_CONTACTS = 10;          // ... so the response rows of the first 10 contacts can be written in the same pass
+static_assert(WSTAGE >= 3 * MERGED_CONTACTS * WPS, "motor staging must not overlap the rows of the merged contacts");
+
+struct Shared {
+  alignas(16) real S[PIH_STATE_WORDS];
+  real LO[NL][3], LA[NL][3];       // world link origins and joint axes
+  real VW[NL][3], VV[NL][3];       // link angular velocity, velocity of the link-origin point
+  real AU[NL][6], ADinv[NL], Au[NL], AR[NL][3];   // U = I^A S, 1/D, u, r = o_L - o_parent
+  real Inv6[36];
+  real u[ND], udot[ND];
+  int c_la[CMAX], c_lb[CMAX], c_key[CMAX];
+  real c_p[CMAX][3], c_n[CMAX][3], c_depth[CMAX], c_mu[CMAX];
+  int nc, nca;
+  real r_lam[NROWC];
+  // packed motor / limit rows (16-byte records => one broadcast ds_read_b128 per row in the PGS loop):
+  //   mrec[m] = {1/(J W), rhs, sqrt(resid)/(J W) (early-exit threshold on |d lambda|), max impulse} ; before build_rows [1] holds the target velocity
+  //   lrec[j] = {rhs lower, rhs upper, J W of arm joint j, -}
+  alignas(16) real mrec[NMOT][4];
+  alignas(16) real lrec[9][4];
+  union { ArenaA a; ArenaB b; };
+};
+// global spill area of one env: response rows and records of contacts CL..CMAX-1
+constexpr int OVF_W_WORDS = 3 * (CMAX - CL) * WPS, OVF_REC_WORDS = (CMAX - CL) * CREC, OVF_WORDS = OVF_W_WORDS + OVF_REC_WORDS;
+struct Ovf { real* base; };
+PIH_HD real* wp_row(Shared& sh, const Ovf& ov, int row) { return row < 3 * CL ? sh.b.Wp[row] : ov.base + (size_t)(row - 3 * CL) * WPS; }
+PIH_HD real* crec_of(Shared& sh, const Ovf& ov, int c) { return c < CL ? sh.b.crec[c] : ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC; }
+PIH_HD real* wmp_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + WSTAGE + j * WMS; }
+PIH_HD real* wma_row(Shared& sh, int j) { return &sh.b.Wp[0][0] + WSTAGE + WMA_OFF + j * 9; }
+
+// ------------------------------------------------------------------------------------------------ kinematics
+// local transform of link L for joint value q (lane = link)
+PIH_HD void local_transform(int L, real q, const real* S, real* T) {
+  int jt = L_JTYPE[L];
+  if (jt == PIH_JT_FLOATING) {
+    Q4 qq; qq.x = S[PIH_S_QUAT]; qq.y = S[PIH_S_QUAT + 1]; qq.z = S[PIH_S_QUAT + 2]; qq.w = S[PIH_S_QUAT + 3];
+    M3 R = q_to_m(qq); stm(T, R); T[9] = S[PIH_S_POS]; T[10] = S[PIH_S_POS + 1]; T[11] = S[PIH_S_POS + 2];
+    return;
+  }
+  M3 Rf = ldm(L_RFIX[L]); V3 ax = ld3(L_AXIS[L]); V3 t = ld3(L_TFIX[L]);
+  if (jt == PIH_JT_REVOLUTE) { M3 R = mul(Rf, axis_angle(ax, q)); stm(T, R); st3(T + 9, t); }
+  else { stm(T, Rf); st3(T + 9, t + q * mul(Rf, ax)); }
+}
+
+PIH_HD void ee_pose(const Shared& sh, V3& p, M3& R) {
+  M3 Rp = ldm(sh.a.LR[PIH_EE_PARENT]);
+  R = mul(Rp, ldm(EE_R)); p = ld3(sh.LO[PIH_EE_PARENT]) + mul(Rp, ld3(EE_T));
+}
+// getLinkState(pipe, grasp_joint_idx)[0:2]: COM frame of pipe_link1 (idx 0) / pipe_link24 (idx 23)
+PIH_HD void tip_pose(const Shared& sh, real* out) {
+  int g = (int)sh.S[PIH_S_GRASP];
+  int L = g == 0 ? ANL : NL - 1;
+  M3 R = ldm(sh.a.LR[L]);
+  V3 p = ld3(sh.LO[L]) + mul(R, mk(0, g == 0 ? (real)0.045 : (real)0.015, 0));
+  Q4 q = m_to_q(R);
+  out[0] = p.x; out[1] = p.y; out[2] = p.z; out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
+}
+
+// ------------------------------------------------------------------------------------------------ IK (p2)
+// Serial revolute chains the IK runs on: the 7 Panda arm joints (envs/utils.py:67) and the 6 UR5 joints (envs/utils.py:79)
+struct PandaChain {
+  static constexpr int N = 7;
+  PIH_HD static const real* rfix(int L) { return L_RFIX[L]; }
+  PIH_HD static const real* tfix(int L) { return L_TFIX[L]; }
+  PIH_HD static const real* axis(int L) { return L_AXIS[L]; }
+  PIH_HD static const real* base_r() { return ARM_BASE_R; }
+  PIH_HD static const real* base_t() { return ZERO3; }
+  PIH_HD static const real* ee_r() { return EE_R; }
+  PIH_HD static const real* ee_t() { return EE_T; }
+};
+struct Ur5Chain {
+  static constexpr int N = 6;
+  PIH_HD static const real* rfix(int L) { return UR5_RFIX[L]; }
+  PIH_HD static const real* tfix(int L) { return UR5_TFIX[L]; }
+  PIH_HD static const real* axis(int L) { return UR5_AXIS[L]; }
+  PIH_HD static const real* base_r() { return IDENT3; }
+  PIH_HD static const real* base_t() { return UR5_BASE_T; }
+  PIH_HD static const real* ee_r() { return UR5_EE_R; }
+  PIH_HD static const real* ee_t() { return UR5_EE_T; }
+};
+// BussIK DLS as driven by pybullet.calculateInverseKinematics without null-space arguments [UNVERIFIED restatement]:
+// dq = (J^T J + d I)^-1 J^T e over the movable DOF (Panda finger columns are zero => 7x7; UR5 6x6), |dq|_inf <= 30 deg.
+// ik_T: LDS scratch [N][12] for the lane-parallel local transforms.
+template <class C, class W> PIH_HD void ik_chain(W& w, real (*ik_T)[12], const Params& P, const real* q0, V3 tpos, Q4 tq, real* qout) {
+  constexpr int N = C::N;
+  real q[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] = q0[i];
+  const real maxstep = (real)(30.0 * 3.14159265358979323846 / 180.0);
+  for (int it = 0; it < P.ikiters; it++) {
+    w.par(N, [&](int L) {
+      real qq = q[0];
+#pragma unroll
+      for (int k = 1; k < N; k++) qq = (L == k) ? q[k] : qq;
+      M3 R = mul(ldm(C::rfix(L)), axis_angle(ld3(C::axis(L)), qq));
+      stm(ik_T[L], R); st3(ik_T[L] + 9, ld3(C::tfix(L)));
+    });
+    V3 a[N], o[N];
+    M3 R = ldm(C::base_r()); V3 org = ld3(C::base_t());
+#pragma unroll
+    for (int L = 0; L < N; L++) {
+      M3 Tl = ldm(ik_T[L]); V3 tl = ld3(ik_T[L] + 9);
+      org = org + mul(R, tl); R = mul(R, Tl);
+      o[L] = org; a[L] = mul(R, ld3(C::axis(L)));     // a revolute axis is invariant under its own rotation
+    }
+    M3 Re = mul(R, ldm(C::ee_r())); V3 p = org + mul(R, ld3(C::ee_t()));
+    Q4 cq = m_to_q(Re);
+    V3 ep = tpos - p;
+    if (norm(ep) < P.ikres) break;
+    Q4 ci; ci.x = -cq.x; ci.y = -cq.y; ci.z = -cq.z; ci.w = cq.w;
+    Q4 dq = q_mul(tq, ci);
+    // Bullet: angle = 2 acos(w) wrapped to (-pi, pi], axis = xyz / sqrt(1 - w^2).  For a unit quaternion this equals
+    // 2 atan2(|xyz|, w) and xyz/|xyz|, which (unlike acos near w = 1) is well conditioned in fp32.
+    V3 dv3 = mk(dq.x, dq.y, dq.z);
+    real sn = norm(dv3), ang = 2 * (real)atan2(sn, dq.w);
+    V3 ax = sn < (real)1e-12 ? mk(1, 0, 0) : ((real)1 / sn) * dv3;
+    if (ang > PIH_PI) ang -= 2 * PIH_PI;
+    V3 er = ang * ax;
+    V3 jl[N];
+    real b[N], A[N][N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { jl[j] = cross(a[j], p - o[j]); b[j] = dot(jl[j], ep) + dot(a[j], er); }
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) A[i][j] = dot(jl[i], jl[j]) + dot(a[i], a[j]) + (i == j ? P.ikdamp : (real)0);
+    // Cholesky (lower) + solve, fully unrolled
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      real s = A[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= A[j][k] * A[j][k];
+      real d = (real)sqrt(s); A[j][j] = d; real di = (real)1 / d;
+#pragma unroll
+      for (int i = j + 1; i < N; i++) {
+        real t = A[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k];
+        A[i][j] = t * di;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) { real s = b[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) s -= A[i][k] * b[k];
+      b[i] = s / A[i][i]; }
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) { real s = b[i];
+#pragma unroll
+      for (int k = i + 1; k < N; k++) s -= A[k][i] * b[k];
+      b[i] = s / A[i][i]; }
+    real mx = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) mx = absr(b[i]) > mx ? absr(b[i]) : mx;
+    real sc = mx > maxstep ? maxstep / mx : (real)1;
+#pragma unroll
+    for (int i = 0; i < N; i++) q[i] += sc * b[i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) qout[i] = q[i];
+}
+
+// ------------------------------------------------------------------------------------------------ reset
+// envs/peg_in_hole.py:227-274 with the RNG draw order of SURVEY.md App. E (own counter RNG).  Wave-uniform.
+PIH_HD void reset_state(real* S, const Params& P, int env_global) {
+  real off0 = S[PIH_S_OFFSET], off1 = S[PIH_S_OFFSET + 1], off2 = S[PIH_S_OFFSET + 2], nbad = S[PIH_S_SPARE];
+  // draw counter = RNG_HI * 2^24 + RNG: two exact fp32 integers (one fp32 word alone is exact only up to 2^24 draws)
+  uint64_t ctr = ((uint64_t)S[PIH_S_RNG_HI] << 24) + (uint64_t)S[PIH_S_RNG];
+  uint64_t seed = P.seed + 1000ULL + (uint64_t)env_global;
+  for (int i = 0; i < PIH_STATE_WORDS; i++) S[i] = 0;
+  S[PIH_S_OFFSET] = off0; S[PIH_S_OFFSET + 1] = off1; S[PIH_S_OFFSET + 2] = off2; S[PIH_S_SPARE] = nbad;
+  for (int i = 0; i < 9; i++) { S[PIH_S_QARM + i] = ARM_REST[i]; S[PIH_S_TARGET + i] = ARM_REST[i]; }
+  const real U = (real)(1.0 / 16777216.0);
+  S[PIH_S_POS] = (real)-0.2 + (real)0.4 * ((real)rng24(seed, ctr++) * U);
+  S[PIH_S_POS + 1] = (real)-0.4 - (real)0.2 * ((real)rng24(seed, ctr++) * U);
+  S[PIH_S_POS + 2] = (real)0.11;
+  S[PIH_S_QUAT + 3] = 1;
+  int k = 5 + (int)(((uint64_t)rng24(seed, ctr++) * 20ULL) >> 24);
+  // partial Fisher-Yates over 24 joint indices, kept as a 24 x 5-bit packed permutation to stay in registers
+  uint64_t lo = 0, hi = 0;   // entries 0..11 in lo, 12..23 in hi (5 bits each)
+  for (int i = 0; i < 12; i++) { lo |= (uint64_t)i << (5 * i); hi |= (uint64_t)(i + 12) << (5 * i); }
+  auto get = [&](int i) -> int { return i < 12 ? (int)((lo >> (5 * i)) & 31) : (int)((hi >> (5 * (i - 12))) & 31); };
+  auto set = [&](int i, int v) {
+    if (i < 12) lo = (lo & ~(31ULL << (5 * i))) | ((uint64_t)v << (5 * i));
+    else hi = (hi & ~(31ULL << (5 * (i - 12)))) | ((uint64_t)v << (5 * (i - 12)));
+  };
+  for (int i = 0; i < k; i++) {
+    int j = i + (int)(((uint64_t)rng24(seed, ctr++) * (uint64_t)(24 - i)) >> 24);
+    int a = get(i), b = get(j); set(i, b); set(j, a);
+  }
+  for (int i = 0; i < k; i++) {
+    real a = (real)(3.14159265358979323846 / 3.0) * ((real)rng24(seed, ctr++) * U);
+    int idx = get(i);
+    if (idx >= 1) S[PIH_S_QJ + idx - 1] = a;
+  }
+  S[PIH_S_GRASP] = (rng24(seed, ctr++) >> 23) ? (real)23 : (real)0;
+  S[PIH_S_RANDY] = (real)-0.03 + (real)0.06 * ((real)rng24(seed, ctr++) * U);
+  S[PIH_S_RNG] = (real)(ctr & 0xFFFFFFull); S[PIH_S_RNG_HI] = (real)((ctr >> 24) & 0xFFFFFFull);
+}
+
+// ------------------------------------------------------------------------------------------------ controller
+// Serial execution context: `par` is a plain loop.  One LANE of pih_pre_kernel runs one env's controller with it (64 envs
+// per wavefront, no wave-uniform replication), and the host emulation uses it for the same function.
+struct Serial {
+  template <class F> PIH_HD void par(int n, F f) {
+#pragma unroll
+    for (int i = 0; i < n; i++) f(i);
+  }
+  PIH_HD void sync() {}
+};
+// end-effector pose of a serial chain
+template <class C> PIH_HD void chain_ee(const real* q, V3& p, M3& Re) {
+  M3 R = ldm(C::base_r()); V3 org = ld3(C::base_t());
+#pragma unroll
+  for (int L = 0; L < C::N; L++) {
+    M3 Tl = mul(ldm(C::rfix(L)), axis_angle(ld3(C::axis(L)), q[L]));
+    org = org + mul(R, ld3(C::tfix(L))); R = mul(R, Tl);
+  }
+  Re = mul(R, ldm(C::ee_r())); p = org + mul(R, ld3(C::ee_t()));
+}
+// getLinkState(pipe, grasp_joint_idx)[0:2] from the state record alone (serial walk down the pipe chain)
+PIH_HD void tip_pose_serial(const real* S, real* out) {
+  const int g = (int)S[PIH_S_GRASP];
+  Q4 qq; qq.x = S[PIH_S_QUAT]; qq.y = S[PIH_S_QUAT + 1]; qq.z = S[PIH_S_QUAT + 2]; qq.w = S[PIH_S_QUAT + 3];
+  M3 R = q_to_m(qq); V3 o = ld3(S + PIH_S_POS);
+  if (g != 0)
+    for (int L = ANL + 1; L < NL; L++) {
+      M3 Tl = mul(ldm(L_RFIX[L]), axis_angle(ld3(L_AXIS[L]), S[PIH_S_QJ + L - ANL - 1]));
+      o = o + mul(R, ld3(L_TFIX[L])); R = mul(R, Tl);
+    }
+  V3 p = o + mul(R, mk(0, g == 0 ? (real)0.045 : (real)0.015, 0));
+  Q4 q = m_to_q(R);
+  out[0] = p.x; out[1] = p.y; out[2] = p.z; out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
+}
+
+// Controller, part 1 (per env, serial): action / state machine -> IK -> joint targets.  Reads and writes the state record
+// only (S[TARGET..], and in scripted mode the state-machine words), so on the GPU it runs one env per LANE in
+// pih_pre_kernel before the step kernel; the IK is 20 strictly sequential 7x7 solves, which as wave-uniform code inside the
+// one-wave-per-env step kernel cost 13 % of the step at 1/64 lane utilisation.
+PIH_HD void controller_targets(real* S, const Params& P, const real* action) {
+  Serial sw;
+  real ikT[7][12];
+  real q[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = S[PIH_S_QARM + i];
+  V3 eep; M3 eeR; chain_ee<PandaChain>(q, eep, eeR);
+  if (P.mode == 0) {
+    // panda_execute, envs/utils.py:60-68
+    V3 tl = mk(action[0] - S[PIH_S_OFFSET], action[1] - S[PIH_S_OFFSET + 1], action[2] - S[PIH_S_OFFSET + 2]);
+    V3 tp = vel_constraint(eep, tl, P.dv);
+    Q4 tq = quat_from_euler(0, -PIH_PI, 0);
+    real qs[7];
+    ik_chain<PandaChain>(sw, ikT, P, q, tp, tq, qs);
+#pragma unroll
+    for (int i = 0; i < 7; i++) S[PIH_S_TARGET + i] = qs[i];
+    S[PIH_S_TARGET + 7] = action[3]; S[PIH_S_TARGET + 8] = action[3];
+  } else {
+    // random_grasp loop body, envs/peg_in_hole.py:53-112 (update_state :206-212, grasp_process :122-204)
+    int st = (int)S[PIH_S_FSM];
+    int nstep = (int)(S[PIH_S_FSMT] * (real)240 + (real)0.5) + 1;      // S[FSMT] holds the state clock in seconds, as the reference does
+    const int st_prev = st;
+    if (nstep >= FSM_STEPS[st]) { st += 1; nstep = 0; if (st >= 10) st = 0; }
+    S[PIH_S_FSM] = (real)st; S[PIH_S_FSMT] = (real)nstep * (real)(1.0 / 240.0);
+    real tip[7]; tip_pose_serial(S, tip);
+    Q4 tornq; tornq.x = tip[3]; tornq.y = tip[4]; tornq.z = tip[5]; tornq.w = tip[6];
+    V3 rv = mul(q_to_m(tornq), mk(0, S[PIH_S_RANDY], 0));
+    V3 tpos = mk(tip[0], tip[1], tip[2]) + rv;
+    V3 tp = vel_constraint(eep, tpos, P.dv);
+    if (st == 2 && st_prev != 2) S[PIH_S_GRASP_ANGLE] = (real)atan2(rv.y, rv.x);   // label angle, envs/peg_in_hole.py:72
+    real yaw = yaw_from_quat(tornq);
+    V3 hole = ld3(HOLE_POS);
+    Q4 tq; tq.x = 0; tq.y = 0; tq.z = 0; tq.w = 1;
+    int do_ik = 0;
+    if (st == 1) { tp.z += (real)0.05; tq = quat_from_euler(0, -PIH_PI, PIH_PI / 2 + yaw); do_ik = 1; }
+    else if (st == 2) { tp.z -= (real)0.01; tq = quat_from_euler(0, -PIH_PI, PIH_PI / 2 + yaw); do_ik = 1; }
+    else if (st == 4) { tp = vel_constraint(eep, hole - mk((real)0.2, 0, 0), P.dv); tq = quat_from_euler(0, -PIH_PI, -PIH_PI); do_ik = 1; }
+    else if (st == 5) { tp = vel_constraint(eep, hole - mk((real)0.04, 0, 0), P.dv); tq = quat_from_euler(0, -PIH_PI, -PIH_PI); do_ik = 1; }
+    else if (st == 6) { tp = hole; tq = quat_from_euler(0, -PIH_PI, -PIH_PI); do_ik = 1; }
+    else if (st == 8) { tp = mk((real)0.2, (real)-0.6, (real)0.4); tq = quat_from_euler(0, -PIH_PI, PIH_PI / 2); do_ik = 1; }
+    if (do_ik) {
+      real qs[7];
+      ik_chain<PandaChain>(sw, ikT, P, q, tp, tq, qs);
+#pragma unroll
+      for (int i = 0; i < 7; i++) S[PIH_S_TARGET + i] = qs[i];
+    }
+    const bool closed = st >= 3 && st < 7;
+    const real ft = closed ? (real)0.006 : (real)0.02;
+    S[PIH_S_TARGET + 7] = ft; S[PIH_S_TARGET + 8] = ft;
+  }
+}
+
+// Controller, part 2 (inside the step kernel): motor rows from the targets in the state record.
+// btMultiBodyJointMotor desired velocity = kp (q* - q)/dt (+ qd - kd qd, kd = 1); default load-time velocity motor
+// (target 0, max impulse 1) on every joint that was never commanded (all 23 pipe joints)
+template <class W> PIH_HD void controller_rows(W& w, Shared& sh, const Params& P) {
+  real* S = sh.S;
+  int posctl_arm = 0; real kp_arm = 0, imp_arm = 1, kp_f = 0, imp_f = 1; int posctl_f = 0;
+  if (P.mode == 0) {
+    posctl_arm = posctl_f = 1; kp_arm = kp_f = 1; imp_arm = imp_f = (real)100000.0 * P.dt;
+  } else {
+    const int st = (int)S[PIH_S_FSM];
+    if (st == 9) S[PIH_S_DONE] = 1;          // set here, not in part 1: the step that reaches state 9 still runs in full
+    if (st >= 1) { posctl_arm = 1; kp_arm = (real)0.1; imp_arm = (real)(5.0 * 240.0) * P.dt; }
+    const bool closed = st >= 3 && st < 7;
+    posctl_f = 1; kp_f = (real)0.1; imp_f = (closed ? (real)20000 : (real)20) * P.dt;
+  }
+  w.par(NMOT, [&](int m) {
+    real vt = 0, imp = 1;
+    if (m < 7) { if (posctl_arm) { vt = kp_arm * (S[PIH_S_TARGET + m] - S[PIH_S_QARM + m]) / P.dt; imp = imp_arm; } }
+    else if (m < 9) { if (posctl_f) { vt = kp_f * (S[PIH_S_TARGET + m] - S[PIH_S_QARM + m]) / P.dt; imp = imp_f; } }
+    sh.mrec[m][1] = vt; sh.mrec[m][3] = imp;
+  });
+}
+
+// ------------------------------------------------------------------------------------------------ collision
+template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
+  const real r = (real)PIH_PIPE_RADIUS, margin = P.margin;
+  w.par(NSAMP, [&](int i) {
+    int L = ANL + SAMP_LINK[i];
+    V3 p = ld3(sh.LO[L]) + mul(ldm(sh.a.LR[L]), mk(0, SAMP_Y[i], 0));
+    st3(sh.a.SP[i], p);
+  });
+  auto emit = [&](int slot, int la, int lb, int key, V3 p, V3 n, real depth, real mu) {
+    sh.c_la[slot] = la; sh.c_lb[slot] = lb; sh.c_key[slot] = key; st3(sh.c_p[slot], p); st3(sh.c_n[slot], n);
+    sh.c_depth[slot] = depth; sh.c_mu[slot] = clampr(mu, -PIH_MAX_FRICTION, PIH_MAX_FRICTION);
+  };
+  w.alloc_reset(0);
+  // table plane: vertices only
+  w.par_all(NSAMP, [&](int i, bool in) {
+    bool valid = false; V3 sp = mk(0, 0, 0); real depth = 0; int L = 0;
+    if (in && SAMP_VERTEX[i]) {
+      sp = ld3(sh.a.SP[i]); depth = sp.z - (real)PIH_TABLE_Z - r; L = ANL + SAMP_LINK[i];
+      valid = depth < margin;
+    }
+    int slot = w.alloc(valid);
+    if (valid && slot < CMAX) {
+      int vi = 0;   // vertex ordinal = key
+      { int s = SAMP_LINK[i]; vi = SAMP_Y[i] > (real)0.02 && s == 23 ? 24 : s; }
+      emit(slot, L, -1, vi, mk(sp.x, sp.y, sp.z - r - (real)0.5 * depth), mk(0, 0, 1), depth, L_MU[L] * (real)PIH_TABLE_MU);
+    }
+  });
+  // hole tube: exact SDF of the solid of revolution of a rectangle in (axial a, radial rho)
+  const real hl = (real)PIH_HOLE_HALFLEN, rcx = (real)(0.5 * (PIH_HOLE_RIN + PIH_HOLE_ROUT)), hw = (real)(0.5 * (PIH_HOLE_ROUT - PIH_HOLE_RIN));
+  w.par_all(NSAMP, [&](int i, bool in) {
+    bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = 0; int L = 0;
+    if (in) {
+      V3 sp = ld3(sh.a.SP[i]); V3 d = sp - ld3(HOLE_POS);
+      real a = d.x, rho = (real)sqrt(d.y * d.y + d.z * d.z);
+      real dx = absr(a) - hl, dy = absr(rho - rcx) - hw;
+      if (!(dx > r + margin || dy > r + margin)) {
+        real sa = a >= 0 ? (real)1 : (real)-1, sr = rho >= rcx ? (real)1 : (real)-1, ga, gr, sdf;
+        if (dx <= 0 && dy <= 0) { if (dx > dy) { ga = sa; gr = 0; sdf = dx; } else { ga = 0; gr = sr; sdf = dy; } }
+        else { real mx = dx > 0 ? dx : 0, my = dy > 0 ? dy : 0; sdf = (real)sqrt(mx * mx + my * my); ga = sa * mx / sdf; gr = sr * my / sdf; }
+        depth = sdf - r;
+        if (depth < margin) {
+          V3 rh = rho > (real)1e-9 ? mk(0, d.y / rho, d.z / rho) : mk(0, 1, 0);
+          n = mk(ga, gr * rh.y, gr * rh.z); p = sp - (r + (real)0.5 * depth) * n; L = ANL + SAMP_LINK[i]; valid = true;
+        }
+      }
+    }
+    int slot = w.alloc(valid);
+    if (valid && slot < CMAX) emit(slot, L, -1, 100 + i, p, n, depth, L_MU[L] * (real)PIH_HOLE_MU);
+  });
+  // p7 attach (envs/peg_in_hole.py:99-104), restated as a ball joint between the grasp point of the grasped pipe link
+  // (childFramePosition = random_vector) and the grasp-target origin (parentFramePosition = 0), active in FSM states 4..6:
+  // one contact whose three rows are bilateral (mu < 0 marks it); emitted before the finger contacts so it is never dropped
+  int nca = 0;
+  {
+    const bool attached = P.mode == 1 && sh.S[PIH_S_FSM] >= 4 && sh.S[PIH_S_FSM] <= 6;
+    const int before = w.alloc_count();
+    w.par_all(1, [&](int i, bool in) {
+      bool valid = in && i == 0 && attached;
+      int slot = w.alloc(valid);
+      if (valid && slot < CMAX) {
+        int g = (int)sh.S[PIH_S_GRASP];
+        int L = g == 0 ? ANL : NL - 1;
+        V3 a1 = ld3(sh.LO[L]) + mul(ldm(sh.a.LR[L]), mk(0, (g == 0 ? (real)0.045 : (real)0.015) + sh.S[PIH_S_RANDY], 0));
+        V3 ee; M3 eR; ee_pose(sh, ee, eR);
+        V3 d = a1 - ee; real dist = norm(d);
+        V3 n = dist > (real)1e-9 ? ((real)1 / dist) * d : mk(1, 0, 0);
+        emit(slot, L, PIH_EE_PARENT, 2000, (real)0.5 * (a1 + ee), n, dist, (real)-1);
+      }
+    });
+    nca += w.alloc_count() - before;
+  }
+  // arm collision spheres vs the table plane (linkA = arm link, linkB = world; keys 3000+): they count against the
+  // arm-contact cap and come before the finger contacts, so a finger-vs-pipe contact is what gets dropped first
+  if (P.armcol) {
+    const int before = w.alloc_count();
+    const int allowed = CAMAX - nca;
+    w.par_all(PIH_ARM_NSPH, [&](int i, bool in) {
+      bool valid = false; V3 cw = mk(0, 0, 0); real depth = 0, rs = 0; int L = 0;
+      if (in) {
+        L = ASPH_LINK[i]; rs = ASPH_R[i];
+        cw = ld3(sh.LO[L]) + mul(ldm(sh.a.LR[L]), ld3(ASPH_C[i]));
+        depth = cw.z - (real)PIH_TABLE_Z - rs;
+        valid = depth < margin;
+      }
+      int slot = w.alloc(valid);
+      if (valid && slot < CMAX && (slot - before) < allowed) emit(slot, L, -1, 3000 + i, mk(cw.x, cw.y, cw.z - rs - (real)0.5 * depth), mk(0, 0, 1), depth, L_MU[L] * (real)PIH_TABLE_MU);
+    });
+    int used = w.alloc_count() - before;
+    if (used > allowed) { used = allowed; w.alloc_reset(before + allowed); }
+    nca += used;
+  }
+  // finger pad boxes (arm links 7, 8)
+  for (int f = 0; f < 2; f++) {
+    const int LF = PIH_FINGER_LINK0 + f;
+    M3 Rf = ldm(sh.a.LR[LF]); V3 bc = ld3(sh.LO[LF]) + mul(Rf, ld3(FBOX_C[f])); V3 bh = ld3(FBOX_H);
+    const int before = w.alloc_count();
+    const int allowed = CAMAX - nca;   // arm-involving contacts are capped
+    w.par_all(NSAMP, [&](int i, bool in) {
+      bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = 0; int L = 0;
+      if (in) {
+        V3 sp = ld3(sh.a.SP[i]); V3 d = sp - bc;
+        if (dot(d, d) <= (real)(0.05 * 0.05)) {
+          V3 pl = tmul(Rf, d);
+          V3 q = mk(clampr(pl.x, -bh.x, bh.x), clampr(pl.y, -bh.y, bh.y), clampr(pl.z, -bh.z, bh.z));
+          bool inside = q.x == pl.x && q.y == pl.y && q.z == pl.z;
+          V3 nl; real sdf;
+          if (inside) {
+            real bx = bh.x - absr(pl.x), by = bh.y - absr(pl.y), bz = bh.z - absr(pl.z);
+            int ax = 0; real best = bx;
+            if (by < best) { best = by; ax = 1; }
+            if (bz < best) { best = bz; ax = 2; }
+            nl = mk(ax == 0 ? (pl.x >= 0 ? (real)1 : (real)-1) : 0, ax == 1 ? (pl.y >= 0 ? (real)1 : (real)-1) : 0, ax == 2 ? (pl.z >= 0 ? (real)1 : (real)-1) : 0);
+            sdf = -best;
+          } else { V3 df = pl - q; sdf = norm(df); nl = ((real)1 / sdf) * df; }
+          depth = sdf - r;
+          if (depth < margin) { n = mul(Rf, nl); p = sp - (r + (real)0.5 * depth) * n; L = ANL + SAMP_LINK[i]; valid = true; }
+        }
+      }
+      int slot = w.alloc(valid);
+      if (valid && slot < CMAX && (slot - before) < allowed) emit(slot, L, LF, 300 + f * NSAMP + i, p, n, depth, L_MU[L] * L_MU[LF]);
+    });
+    int used = w.alloc_count() - before;
+    if (used > allowed) { used = allowed; w.alloc_reset(before + allowed); }   // the dropped ones are the tail of this pass
+    nca += used;
+  }
+  // pipe self collision: capsule segments s < t, non adjacent (253 pairs, enumerated in key order)
+  if (P.selfcol) {
+    w.par_all(253, [&](int idx, bool in) {
+      bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = 0; int s = 0, t = 0;
+      if (in) {
+        // idx -> (s,t): row s has (22 - s) entries (t = s+2..23)
+        int rem = idx; s = 0;
+        while (rem >= 22 - s) { rem -= 22 - s; s++; }
+        t = s + 2 + rem;
+        // vertex v = first sample of segment v (v<24) / last sample (v=24): sample index of vertex v
+        auto vtx = [&](int v) -> V3 { int si = v == 0 ? 0 : (v == 24 ? NSAMP - 1 : 7 + 5 * (v - 1)); return ld3(sh.a.SP[si]); };
+        V3 p1 = vtx(s), q1 = vtx(s + 1), p2 = vtx(t), q2 = vtx(t + 1);
+        V3 dm = (p1 + q1) - (p2 + q2);
+        if (dot(dm, dm) <= (real)(4 * 0.12 * 0.12)) {
+          V3 d1 = q1 - p1, d2 = q2 - p2, rr = p1 - p2;
+          real a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, rr), ss, tt;
+          const real EPS = (real)1e-12;
+          if (a <= EPS && e <= EPS) { ss = tt = 0; }
+          else if (a <= EPS) { ss = 0; tt = clampr(f / e, 0, 1); }
+          else {
+            real c = dot(d1, rr);
+            if (e <= EPS) { tt = 0; ss = clampr(-c / a, 0, 1); }
+            else {
+              real b = dot(d1, d2), den = a * e - b * b;
+              ss = den > EPS ? clampr((b * f - c * e) / den, 0, 1) : (real)0;
+              tt = (b * ss + f) / e;
+              if (tt < 0) { tt = 0; ss = clampr(-c / a, 0, 1); } else if (tt > 1) { tt = 1; ss = clampr((b - c) / a, 0, 1); }
+            }
+          }
+          V3 c1 = p1 + ss * d1, c2 = p2 + tt * d2, d = c1 - c2;
+          real dist = norm(d); depth = dist - 2 * r;
+          if (depth < margin && dist >= (real)1e-9) { n = ((real)1 / dist) * d; p = (real)0.5 * (c1 + c2); valid = true; }
+        }
+      }
+      int slot = w.alloc(valid);
+      if (valid && slot < CMAX) emit(slot, ANL + s, ANL + t, 1000 + s * 24 + t, p, n, depth, L_MU[ANL + s] * L_MU[ANL + t]);
+    });
+  }
+  int nc = w.alloc_count(); if (nc > CMAX) nc = CMAX;
+  sh.nc = nc; sh.nca = nca;
+}
+
+// ------------------------------------------------------------------------------------------------ ABA helpers
+// root of the pipe: invert the 6x6 articulated inertia held in Mx (8-word rows: 6 x 6 entries in order angular, linear; column 6
+// = bias force) by Gauss-Jordan (SPD), wave-uniform; leaves the inverse in sh.Inv6 and the root bias force in rootp
+PIH_HD void aba_root_inverse(Shared& sh, const real* Mx, areal* rootp) {
+  areal Mq[6][6], Iv[6][6];
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { Mq[i][j] = Mx[8 * i + j]; Iv[i][j] = i == j ? (areal)1 : (areal)0; }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    areal pv = (areal)1 / Mq[k][k];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { Mq[k][j] *= pv; Iv[k][j] *= pv; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) if (i != k) {
+      areal f = Mq[i][k];
+#pragma unroll
+      for (int j = 0; j < 6; j++) { Mq[i][j] -= f * Mq[k][j]; Iv[i][j] -= f * Iv[k][j]; }
+    }
+  }
+  for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) sh.Inv6[6 * i + j] = (real)Iv[i][j]; rootp[i] = Mx[8 * i + 6]; }
+}
+// word of the packed record IAP[L] (A6 sym | B9 | C6 sym | p_a 3 | p_l 3 | 0) that holds entry (i, j) of the 6 x 8 array
+// [ I^A | p^A | - ] of the inward sweep
+PIH_HD int aba_own_word(int i, int j) {
+  const int ii = i < 3 ? i : i - 3, jj = j < 3 ? j : j - 3;
+  const int sym = ii == jj ? ii : ii + jj + 2;                      // xx yy zz xy xz yz
+  if (i >= 6 || j >= 7) return 27;
+  if (j == 6) return 21 + i;
+  if (i < 3 && j < 3) return sym;
+  if (i >= 3 && j >= 3) return 15 + sym;
+  if (i < 3) return 6 + 3 * i + jj;                                 // B[i][j-3]
+  return 6 + 3 * j + ii;                                            // B^T: B[j][i-3]
+}
+static_assert(NROWC >= 144, "scratch of the inward sweep aliases r_lam");
+
+// the wave layer keeps the 32 motor response rows (lane = DOF) across the contact-row pass: see pull_motor_rows in pih_wave.h
+// ------------------------------------------------------------------------------------------------ constraint rows
+// Unit-impulse response of the articulated system (lane = row): impulse `dirA` at point p on link la, `-dirA` on lb
+// (either may be -1), or a unit joint impulse on the joint of link jm.  Writes the arm part (9) and pipe part (29)
+// of W = M^-1 J^T and returns J W (the inverse effective mass of the row).
+struct RowOut { real* wa; real* wp; };
+PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, RowOut out, V3* dvp_out = nullptr) {
+  real jw = 0; V3 dvp = mk(0, 0, 0);
+  bool arm = (la >= 0 && la < ANL) || (lb >= 0 && lb < ANL) || (jm >= 0 && jm < ANL);
+  bool obj = (la >= ANL) || (lb >= ANL) || (jm >= ANL);
+  if (arm && out.wa) {
+    V3 Qa[ANL], Ql[ANL]; real uu[ANL];
+#pragma unroll
+    for (int L = 0; L < ANL; L++) { Qa[L] = mk(0, 0, 0); Ql[L] = mk(0, 0, 0); }
+#pragma unroll
+    for (int L = ANL - 1; L >= 0; L--) {
+      if (L == la) { Qa[L] = Qa[L] + cross(p - ld3(sh.LO[L]), dir); Ql[L] = Ql[L] + dir; }
+      if (L == lb) { Qa[L] = Qa[L] - cross(p - ld3(sh.LO[L]), dir); Ql[L] = Ql[L] - dir; }
+      V3 a = ld3(sh.LA[L]);
+      constexpr int JT[ANL] = {0, 0, 0, 0, 0, 0, 0, 1, 1};
+      constexpr int PAR[ANL] = {-1, 0, 1, 2, 3, 4, 5, 6, 6};
+      real u = (L == jm ? (real)1 : (real)0) + (JT[L] == 0 ? dot(a, Qa[L]) : dot(a, Ql[L]));
+      uu[L] = u;
+      if (PAR[L] >= 0) {
+        real ud = u * sh.ADinv[L];
+        V3 qa = Qa[L] - ud * ld3(sh.AU[L]), ql = Ql[L] - ud * ld3(sh.AU[L] + 3);
+        Qa[PAR[L]] = Qa[PAR[L]] + qa + cross(ld3(sh.AR[L]), ql); Ql[PAR[L]] = Ql[PAR[L]] + ql;
+      }
+    }
+    V3 dw[ANL], dvv[ANL];
+#pragma unroll
+    for (int L = 0; L < ANL; L++) {
+      constexpr int JT[ANL] = {0, 0, 0, 0, 0, 0, 0, 1, 1};
+      constexpr int PAR[ANL] = {-1, 0, 1, 2, 3, 4, 5, 6, 6};
+      V3 aa = mk(0, 0, 0), ll = mk(0, 0, 0);
+      if (PAR[L] >= 0) { aa = dw[PAR[L]]; ll = dvv[PAR[L]] + cross(aa, ld3(sh.AR[L])); }
+      real dq = (uu[L] - dot(ld3(sh.AU[L]), aa) - dot(ld3(sh.AU[L] + 3), ll)) * sh.ADinv[L];
+      V3 a = ld3(sh.LA[L]);
+      if (JT[L] == 0) { dw[L] = aa + dq * a; dvv[L] = ll; } else { dw[L] = aa; dvv[L] = ll + dq * a; }
+      out.wa[L] = dq;
+      if (L == jm) jw += dq;
+      if (L == la) dvp = dvp + (dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
+      if (L == lb) dvp = dvp - (dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
+    }
+  }
+  if (obj && out.wp) {
+    V3 Qa = mk(0, 0, 0), Ql = mk(0, 0, 0); real uu[ONL];
+#pragma unroll
+    for (int j = ONL - 1; j >= 0; j--) {
+      const int L = ANL + j;
+      if (L == la) { Qa = Qa + cross(p - ld3(sh.LO[L]), dir); Ql = Ql + dir; }
+      if (L == lb) { Qa = Qa - cross(p - ld3(sh.LO[L]), dir); Ql = Ql - dir; }
+      if (j > 0) {
+        V3 a = ld3(sh.LA[L]);
+        real u = (L == jm ? (real)1 : (real)0) + dot(a, Qa);
+        uu[j] = u;
+        real ud = u * sh.ADinv[L];
+        V3 qa = Qa - ud * ld3(sh.AU[L]), ql = Ql - ud * ld3(sh.AU[L] + 3);
+        Qa = qa + cross(ld3(sh.AR[L]), ql); Ql = ql;
+      }
+    }
+    // root: (alpha, v) = Inv6 * Q
+    real Q[6] = {Qa.x, Qa.y, Qa.z, Ql.x, Ql.y, Ql.z}, x[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { real s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += sh.Inv6[6 * i + k] * Q[k];
+      x[i] = s; }
+    V3 dw = mk(x[0], x[1], x[2]), dvv = mk(x[3], x[4], x[5]);
+    out.wp[0] = dvv.x; out.wp[1] = dvv.y; out.wp[2] = dvv.z; out.wp[3] = dw.x; out.wp[4] = dw.y; out.wp[5] = dw.z;
+    if (ANL == la) dvp = dvp + (dvv + cross(dw, p - ld3(sh.LO[ANL])));
+    if (ANL == lb) dvp = dvp - (dvv + cross(dw, p - ld3(sh.LO[ANL])));
+#pragma unroll
+    for (int j = 1; j < ONL; j++) {
+      const int L = ANL + j;
+      V3 ll = dvv + cross(dw, ld3(sh.AR[L]));
+      real dq = (uu[j] - dot(ld3(sh.AU[L]), dw) - dot(ld3(sh.AU[L] + 3), ll)) * sh.ADinv[L];
+      dw = dw + dq * ld3(sh.LA[L]); dvv = ll;
+      out.wp[5 + j] = dq;
+      if (L == jm) jw += dq;
+      if (L == la) dvp = dvp + (dvv + cross(dw, p - ld3(sh.LO[L])));
+      if (L == lb) dvp = dvp - (dvv + cross(dw, p - ld3(sh.LO[L])));
+    }
+  }
+  if (dvp_out) *dvp_out = dvp;   // relative velocity change at the contact point per unit impulse along dir
+  return jw + dot(dir, dvp);
+}
+
+PIH_HD V3 point_vel(const Shared& sh, int L, V3 p) { return ld3(sh.VV[L]) + cross(ld3(sh.VW[L]), p - ld3(sh.LO[L])); }
+
+// motor response rows held per lane (lane = DOF): arm lanes hold column d of the 9x9 arm block, pipe lanes column d-9 of
+// the 23 x 29 pipe block.  On the GPU these stay in registers across the contact-row pass (their LDS words are reused).
+struct MotorW { real w[PIH_OBJ_NJ]; };
+
+template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, const Ovf& ov, MotorW& mw) {
+  const real dt = P.dt;
+  // link velocities after the free update (contact / motor right-hand sides)
+  link_velocities(w, sh);
+  // Response rows (lane = row): global row g < 32 is a motor row (unit joint impulse; the limit rows share its W and
+  // 1/(J W)), row 32 + 3c + k is row k of contact c (k = 0 normal, 1/2 friction directions).  ONE call site of response()
+  // serves both kinds with per-lane arguments, and the first pass takes the 32 motor rows together with the first 10 contacts
+  // (30 rows: their response rows end below the words the motor rows are staged in), so an env with <= 10 contacts pays for
+  // one sweep of the articulated system instead of two.
+  const int nrows = NMOT + 3 * sh.nc;
+  constexpr int FIRST = NMOT + 3 * MERGED_CONTACTS;
+#pragma nounroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int g0 = pass == 0 ? 0 : FIRST, g1 = pass == 0 ? (nrows < FIRST ? nrows : FIRST) : nrows;
+    if (g1 > g0) w.par(g1 - g0, [&](int i) {
+      const int g = g0 + i;
+      const bool ismotor = g < NMOT;
+      const int row = ismotor ? 0 : g - NMOT, c = row / 3, k = row - 3 * c;
+      int la = -1, lb = -1, jm = -1;
+      V3 p = mk(0, 0, 0), dir = mk(0, 0, 0);
+      RowOut o; o.wa = nullptr; o.wp = nullptr;
+      if (ismotor) {
+        jm = g < 9 ? g : ANL + 1 + (g - 9);
+        if (g < 9) o.wa = wma_row(sh, g); else o.wp = wmp_row(sh, g - 9);
+      } else {
+        la = sh.c_la[c]; lb = sh.c_lb[c];
+        V3 n = ld3(sh.c_n[c]); p = ld3(sh.c_p[c]);
+        V3 t1, t2; plane_space(n, t1, t2);
+        dir = k == 0 ? n : (k == 1 ? t1 : t2);
+        // one full response row per contact row: [arm DOF 0..8 | pipe DOF 9..37 | 0]; the side a contact does not touch is zeroed
+        real* wr = wp_row(sh, ov, row);
+        o.wa = wr; o.wp = wr + 9;
+        if (!(la < ANL || (lb >= 0 && lb < ANL))) { for (int j = 0; j < 9; j++) wr[j] = 0; }
+        if (!(la >= ANL || lb >= ANL)) { for (int j = 9; j < ND; j++) wr[j] = 0; }
+        wr[ND] = 0;
+      }
+      V3 dvp;
+      const real jw = response(sh, la, lb, p, dir, jm, o, &dvp);
+      const real di = (real)1 / jw;
+      if (ismotor) {
+        const int d = link_dof(jm);
+        sh.mrec[g][0] = di; sh.mrec[g][1] = (sh.mrec[g][1] - sh.u[d]) * di; sh.mrec[g][2] = (real)sqrt(P.resid) * di;
+        if (g < 9) sh.lrec[g][2] = jw;
+      } else {
+        real* R = crec_of(sh, ov, c);
+        V3 vr = point_vel(sh, la, p);
+        if (lb >= 0) vr = vr - point_vel(sh, lb, p);
+        real ju = dot(dir, vr);
+        real lam = 0, rhs;
+        if (k == 0) {
+          real pen = sh.c_depth[c] + P.slop;
+          real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
+          if (sh.c_mu[c] < 0) vb = -P.erp * sh.c_depth[c] / dt;   // attach: close the gap with ERP, both signs allowed
+          rhs = (vb - ju) * di;
+          int ncache = (int)sh.S[PIH_S_CACHE_N]; real key = (real)sh.c_key[c];
+          for (int q = 0; q < ncache; q++) if (sh.S[PIH_S_CACHE_KEY + q] == key) { lam = P.warm * sh.S[PIH_S_CACHE_LAMBDA + q]; break; }
+          const bool bil = sh.c_mu[c] < 0;
+          R[0] = p.x; R[1] = p.y; R[2] = p.z; R[3] = bil ? -PIH_BIG : (real)0; R[4] = bil ? PIH_BIG : (real)0; R[5] = sh.c_mu[c]; R[6] = 0; R[7] = 0;
+        } else rhs = -ju * di;
+        R[8 + 4 * k] = dir.x; R[9 + 4 * k] = dir.y; R[10 + 4 * k] = dir.z; R[11 + 4 * k] = di;
+        R[20 + k] = rhs;
+        if (k < 2) { R[26 + 3 * k] = dvp.x; R[27 + 3 * k] = dvp.y; R[28 + 3 * k] = dvp.z; }
+        sh.r_lam[row] = lam;
+      }
+    });
+    if (pass == 0) {
+      w.par(NLIM, [&](int k) {
+        int L = k >> 1, side = k & 1;
+        real q = sh.S[PIH_S_QARM + L];
+        real pen = side == 0 ? q - L_LO[L] : L_HI[L] - q;
+        real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
+        real sg = side == 0 ? (real)1 : (real)-1;
+        sh.lrec[L][side] = (vb - sg * sh.u[L]) * sh.mrec[L][0];
+      });
+      // pull the motor rows out of the staging words before the contact rows of the second pass overwrite them
+      pull_motor_rows(w, sh, mw);
+    }
+  }
+  // cross terms of each contact block (lane = contact)
+  w.par(sh.nc, [&](int c) {
+    real* R = crec_of(sh, ov, c);
+    V3 t1 = ld3(R + 12), t2 = ld3(R + 16), dn = ld3(R + 26), d1 = ld3(R + 29);
+    R[23] = dot(t1, dn); R[24] = dot(t2, dn); R[25] = dot(t2, d1);
+    R[26] = sh.r_lam[3 * c]; R[27] = 0; R[28] = 0;   // multipliers (n, t1, t2) live in the record from here on (GPU PGS)
+    { const real sr = (real)sqrt(P.resid); R[29] = sr * R[11]; R[30] = sr * R[15]; R[31] = sr * R[19]; }   // early-exit thresholds sqrt(resid) * dinv
+  });
+}
+
+// Jacobian entry of DOF d for a translational row (point p on link la minus link lb, direction dir), from the
+// DOF's own axis/origin: revolute-like dir.(a x (p - o)), prismatic-like dir.a
+struct DofGeom { V3 a, o; int L; int kind; };   // kind: 0 rev-like, 1 pris-like, 2 unused lane
+PIH_HD DofGeom dof_geom(const Shared& sh, int d) {
+  DofGeom g; g.a = mk(0, 0, 0); g.o = mk(0, 0, 0); g.L = 0; g.kind = 2;
+  if (d < 9) { g.L = d; g.a = ld3(sh.LA[d]); g.o = ld3(sh.LO[d]); g.kind = d < 7 ? 0 : 1; }
+  else if (d < 15) { int k = d - 9; g.L = ANL; g.o = ld3(sh.LO[ANL]); int kk = k % 3; g.a = mk(kk == 0, kk == 1, kk == 2); g.kind = k < 3 ? 1 : 0; }
+  else if (d < ND) { g.L = d - 5; g.a = ld3(sh.LA[g.L]); g.o = ld3(sh.LO[g.L]); g.kind = 0; }
+  return g;
+}
+PIH_HD bool is_anc(int L, int X) {   // is the joint of link L on the path from link X to its root (inclusive)?
+  if (X < 0) return false;
+  if (L < ANL) return X < ANL && ((L <= 6 && L <= X) || L == X);
+  return X >= ANL && L <= X;
+}
+PIH_HD real jac_entry(const DofGeom& g, int la, int lb, V3 p, V3 dir) {
+  if (g.kind == 2) return 0;
+  real s = (is_anc(g.L, la) ? (real)1 : (real)0) - (is_anc(g.L, lb) ? (real)1 : (real)0);
+  if (s == 0) return 0;
+  real v = g.kind == 0 ? dot(dir, cross(g.a, p - g.o)) : dot(dir, g.a);
+  return s * v;
+}
+
+}  // namespace pih

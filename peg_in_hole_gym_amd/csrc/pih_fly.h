@@ -18,7 +18,7 @@
 // responses from the same articulated inertias; sequential-impulse PGS over (motor, lower limit, upper limit) per joint, then
 // the contact normals.  The oracle derives the same physics by RNEA + dense Cholesky.
 #pragma once
-#include "pih_device.h"
+#include "pih_common.h"
 
 namespace pih {
 namespace fly {

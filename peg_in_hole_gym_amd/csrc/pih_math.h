@@ -1,24 +1,27 @@
-// pih_math.h -- small fixed-size math used by the per-env step (device code; also compiled for the host by the
-// test-only emulation harness in tests/emul, where `real` may be double).
+// pih_math.h -- small fixed-size math used by the per-env step.
+// Platform section: the product is gfx950 device code (real = float, device intrinsics).  A host harness (tests/emul) may define
+// the same few names itself -- `real`, PIH_HD / PIH_NOINL / PIH_CONST and finite_small / med3_ / max_ / sincos_ / acos_ in
+// namespace pih -- and set PIH_PLATFORM_DEFINED before including this header; nothing host-specific lives in the product tree.
 #pragma once
 #include <math.h>
 #include <stdint.h>
 
-#ifdef PIH_HOST_EMUL
-#ifndef PIH_REAL
-#define PIH_REAL float
-#endif
-typedef PIH_REAL real;
-#define PIH_HD inline
-#define PIH_NOINL inline
-#define PIH_CONST static const
-#else
+#ifndef PIH_PLATFORM_DEFINED
 #include <hip/hip_runtime.h>
 typedef float real;
 #define PIH_HD __device__ __forceinline__
 // (measured: a non-inlined phase loses the LDS address space of `Shared&` and falls back to flat loads: 45 % slower PGS)
 #define PIH_NOINL __device__ __attribute__((noinline))
 #define PIH_CONST static __device__ __constant__ const
+namespace pih {
+// |x| < 1e15 and not NaN/Inf, tested on the bit pattern so that it survives -ffast-math (finite-math assumptions)
+PIH_HD bool finite_small(float x) { return (__builtin_bit_cast(unsigned, x) & 0x7fffffffu) <= 0x58635fa9u; }   // 0x58635fa9 = 1e15f
+// single-instruction clamp / max (v_med3_f32 / v_max_f32); the ?: forms compile to cmp + cndmask pairs
+PIH_HD real med3_(real x, real lo, real hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+PIH_HD real max_(real a, real b) { return __builtin_fmaxf(a, b); }
+PIH_HD void sincos_(float a, float* s, float* c) { sincosf(a, s, c); }
+PIH_HD float acos_(float a) { return acosf(a); }
+}  // namespace pih
 #endif
 
 namespace pih {
@@ -39,31 +42,6 @@ PIH_HD real rsqrt_(real x) { return (real)1 / (real)sqrt(x); }
 PIH_HD real norm(V3 a) { return (real)sqrt(dot(a, a)); }
 PIH_HD real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 PIH_HD real absr(real x) { return x < 0 ? -x : x; }
-// |x| < 1e15 and not NaN/Inf, tested on the bit pattern so that it survives -ffast-math (finite-math assumptions)
-#ifdef PIH_HOST_EMUL
-PIH_HD bool finite_small(double x) { return x == x && (x < 0 ? -x : x) <= 1e15; }
-PIH_HD bool finite_small(float x) { return x == x && (x < 0 ? -x : x) <= 1e15f; }
-#else
-PIH_HD bool finite_small(float x) { return (__builtin_bit_cast(unsigned, x) & 0x7fffffffu) <= 0x58635fa9u; }   // 0x58635fa9 = 1e15f
-#endif
-// single-instruction clamp / max on the GPU (v_med3_f32 / v_max_f32); the ?: forms compile to cmp + cndmask pairs
-#ifdef PIH_HOST_EMUL
-PIH_HD real med3_(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
-PIH_HD real max_(real a, real b) { return a > b ? a : b; }
-#else
-PIH_HD real med3_(real x, real lo, real hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
-PIH_HD real max_(real a, real b) { return __builtin_fmaxf(a, b); }
-#endif
-
-#ifdef PIH_HOST_EMUL
-PIH_HD void sincos_(double a, double* s, double* c) { *s = sin(a); *c = cos(a); }
-PIH_HD void sincos_(float a, float* s, float* c) { *s = sinf(a); *c = cosf(a); }
-PIH_HD double acos_(double a) { return acos(a); }
-PIH_HD float acos_(float a) { return acosf(a); }
-#else
-PIH_HD void sincos_(float a, float* s, float* c) { sincosf(a, s, c); }
-PIH_HD float acos_(float a) { return acosf(a); }
-#endif
 
 // 3x3 row-major
 struct M3 { real m[9]; };

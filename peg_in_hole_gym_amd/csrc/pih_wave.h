@@ -1,0 +1,446 @@
+// pih_wave.h -- the gfx950 wave layer of the per-env step: ONE WAVEFRONT (64 lanes, one workgroup) PER ENV.
+// The wave context (`Wave`: lane-parallel loops, ballot/popcount stream compaction, shader-clock stamps) and the phases written
+// directly with wave primitives: DPP row reductions, ds_bpermute lane exchanges, v_readlane broadcasts, inline v_add_f32_dpp
+// row_bcast, 16-byte LDS broadcasts -- forward kinematics as a prefix product of rigid transforms, link velocities as prefix
+// sums, the entry-parallel inward sweep of the articulated-body algorithm, and the sequential-impulse PGS.
+#pragma once
+#include "pih_common.h"
+
+namespace pih {
+
+struct Wave {
+  int l;
+  int counter;
+  static constexpr bool controller_inline = false;          // the controller runs in pih_pre_kernel, one env per lane
+  real* dbg = nullptr; int dbgmode = 0; long long t0 = 0, t1 = 0;   // diagnostic shader-clock stamps (config.debug == 2; never read by the kernel)
+  PIH_HD void stamp(int k) { if (dbg && dbgmode == 2) { long long t = __builtin_readcyclecounter(); if (l == 0) dbg[900 + k] = (real)(t - t0); t0 = t; } }   // sub-phases
+  PIH_HD void phase_begin() { if (dbg && dbgmode == 2) t1 = __builtin_readcyclecounter(); }
+  PIH_HD void phase(int k) { if (dbg && dbgmode == 2) { long long t = __builtin_readcyclecounter(); if (l == 0) dbg[900 + k] = (real)(t - t1); t1 = t; } }
+  PIH_HD int lane() const { return l; }
+  PIH_HD void sync() { __syncthreads(); }
+  template <class F> PIH_HD void par(int n, F f) {
+    __syncthreads();
+    for (int b = 0; b < n; b += 64) { int i = b + l; if (i < n) f(i); }
+    __syncthreads();
+  }
+  // all lanes call f(i, in_range) for every chunk so that wave collectives inside f are legal
+  template <class F> PIH_HD void par_all(int n, F f) {
+    __syncthreads();
+    for (int b = 0; b < n; b += 64) { int i = b + l; f(i, i < n); }
+    __syncthreads();
+  }
+  PIH_HD void alloc_reset(int base) { counter = base; }
+  PIH_HD int alloc_count() const { return counter; }
+  PIH_HD int alloc(bool valid) {   // must be reached by all 64 lanes
+    unsigned long long m = __ballot(valid);
+    int slot = counter + __popcll(m & ((1ull << l) - 1ull));
+    counter += __popcll(m);
+    return valid ? slot : -1;
+  }
+};
+// ------------------------------------------------------------------------------------------------ cross-lane helpers
+PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane must be wave-uniform): v_readlane_b32
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+template <int CTRL> PIH_HD real dpp_add(real x) {   // x + x[dpp-permuted lane]  (v_add_f32_dpp)
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+PIH_HD real sum8(real x) {               // sum over each aligned group of 8 lanes, result in all 8
+  x = dpp_add<0xB1>(x);                  // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);                  // quad_perm [2,3,0,1]
+  return dpp_add<0x141>(x);              // row_half_mirror
+}
+PIH_HD real from_lane(real v, int byte_addr) {   // v of lane byte_addr / 4 (per-lane source): ds_bpermute_b32, no LDS memory, no VALU slot
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+// ------------------------------------------------------------------------------------------------ forward kinematics
+// GPU form: lane = link.  The world pose of a link is the product of the local transforms along its chain, i.e. an inclusive
+// prefix "product" of rigid transforms: five Hillis-Steele steps (12 ds_bpermute + 39 FMA each) instead of a 33-link serial
+// composition, and the pose never leaves the lane's registers before the world axes / rotated inertias are written.
+// Out-of-chain sources read lane 63, which holds the identity.  Finger 8 is a child of link 6, not of finger 7: it takes
+// finger 7's position in the chain order.  The arm's base rotation is folded into link 0's local transform.
+PIH_HD int lane_byte(int lane) { return 4 * lane; }
+PIH_HD void fk_all(Wave& w, Shared& sh) {
+  w.sync();
+  const int lane = w.lane();
+  const bool active = lane < NL;
+  const int L = active ? lane : NL - 1;
+  M3 R = ldm(IDENT3); V3 o = mk(0, 0, 0);
+  if (active) {
+    real T[12];
+    const real q = L < ANL ? sh.S[PIH_S_QARM + L] : (L == ANL ? (real)0 : sh.S[PIH_S_QJ + L - ANL - 1]);
+    local_transform(L, q, sh.S, T);
+    R = ldm(T); o = ld3(T + 9);
+    if (L == 0) { const M3 B = ldm(ARM_BASE_R); o = mul(B, o); R = mul(B, R); }
+  }
+  const int cs = L < ANL ? 0 : ANL;
+  const int vidx = L == ANL - 1 ? ANL - 2 : lane;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const int src = vidx - off;
+    const int sb = lane_byte((active && src >= cs) ? src : 63);
+    M3 Rs; V3 os;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rs.m[k] = from_lane(R.m[k], sb);
+    os = mk(from_lane(o.x, sb), from_lane(o.y, sb), from_lane(o.z, sb));
+    o = os + mul(Rs, o); R = mul(Rs, R);
+  }
+  if (active) {
+    stm(sh.a.LR[L], R); st3(sh.LO[L], o);
+    st3(sh.LA[L], mul(R, ld3(L_AXIS[L])));
+    st3(sh.a.LRC[L], mul(R, ld3(L_COM[L])));
+    sts3(sh.a.LIC[L], rot_sym(R, lds3(L_INERTIA[L])));
+  }
+  w.sync();
+}
+// ------------------------------------------------------------------------------------------------ link velocities
+// link velocities from the generalized velocity sh.u: omega_L and the velocity of the link-origin point
+// The same recurrences as two inclusive prefix sums along the chains (lane = link): omega_L = sum over the path of the joint
+// angular rates, v_L = sum over the path of (omega_parent x (o_L - o_parent) + prismatic rate).  Hillis-Steele steps through
+// ds_bpermute (5 steps cover the 24-link pipe); finger 8 is a child of link 6, not of finger 7, so it drops finger 7's terms.
+PIH_HD V3 from_lane3(V3 v, int byte_addr) { return mk(from_lane(v.x, byte_addr), from_lane(v.y, byte_addr), from_lane(v.z, byte_addr)); }
+PIH_HD V3 chain_prefix_sum(V3 t, int lane, int chain_start) {
+  V3 acc = t;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const int src = lane - off;
+    const V3 o = from_lane3(acc, 4 * (src < 0 ? 0 : src));
+    if (src >= chain_start) acc = acc + o;
+  }
+  return acc;
+}
+PIH_HD void link_velocities_scan(Shared& sh, int lane) {
+  const bool active = lane < NL;
+  const int L = active ? lane : NL - 1;
+  const int jt = L == ANL ? PIH_JT_FLOATING : ((L == ANL - 1 || L == ANL - 2) ? PIH_JT_PRISMATIC : PIH_JT_REVOLUTE);
+  const int par = (L == 0 || L == ANL) ? -1 : (L == ANL - 1 ? ANL - 3 : L - 1);
+  const int cs = L < ANL ? 0 : ANL, d = link_dof(L);
+  const V3 aq = sh.u[d] * ld3(sh.LA[L]);
+  const V3 tw = jt == PIH_JT_FLOATING ? ld3(&sh.u[d + 3]) : (jt == PIH_JT_REVOLUTE ? aq : mk(0, 0, 0));
+  V3 wv = chain_prefix_sum(tw, lane, cs);
+  const V3 tw7 = from_lane3(tw, 4 * (ANL - 2));
+  if (L == ANL - 1) wv = wv - tw7;
+  const V3 wp = from_lane3(wv, 4 * (par < 0 ? 0 : par));
+  V3 tv;
+  if (jt == PIH_JT_FLOATING) tv = ld3(&sh.u[d]);
+  else {
+    tv = jt == PIH_JT_PRISMATIC ? aq : mk(0, 0, 0);
+    if (par >= 0) tv = tv + cross(wp, ld3(sh.LO[L]) - ld3(sh.LO[par]));
+  }
+  V3 vv = chain_prefix_sum(tv, lane, cs);
+  const V3 tv7 = from_lane3(tv, 4 * (ANL - 2));
+  if (L == ANL - 1) vv = vv - tv7;
+  if (active) { st3(sh.VW[L], wv); st3(sh.VV[L], vv); }
+}
+PIH_HD void link_velocities(Wave& w, Shared& sh) { w.sync(); link_velocities_scan(sh, w.lane()); w.sync(); }
+
+// ------------------------------------------------------------------------------------------------ ABA inward sweep
+// Inward sweep of the articulated-body algorithm, LANE = ENTRY of the articulated inertia: lane l < 48 owns entry
+// (i, j) = (l >> 3, l & 7) of the 6 x 8 array [ I^A (6 x 6, rows/cols 0-2 angular, 3-5 linear, i.e. [[A, B], [B^T, C]]) |
+// p^A (column 6) | - ].  Per link:
+//   1. m = own inertia of the link + what the child handed up
+//   2. U = I^A S  (S = [a; 0] revolute, [0; a] prismatic), D = S.U, u = tau - S.p^A
+//   3. I^a = I^A - U U^T / D ;  column 6 = p^a = p^A + I^a c + U u / D
+//   4. translate to the parent's origin (r = o_L - o_parent):  B' = B + [r]x C,  A' = A + [r]x B^T - B' [r]x,
+//      p_a' = p_a + r x p_l   (entry formulas: ([r]x X)_ij = r_i1 X_i2,j - r_i2 X_i1,j ; (X [r]x)_ij = X_i,j1 r_j2 - X_i,j2 r_j1)
+// The arm's two fingers (links 7, 8) both feed link 6: finger 8's hand-up is parked in a register until finger 7 is done.
+PIH_HD void aba_inward(Wave& w, Shared& sh, areal* rootp) {
+  real* const Mx = sh.r_lam;      // 48 words of scratch for the root inversion (r_lam is dead until the rows are built)
+  // GPU form of the same four steps: the entry stays in a register of its lane; row sums are DPP reductions over the 8-lane
+  // row group, entries of other rows come through ds_bpermute (no LDS memory, no VALU slot), wave-uniform scalars (D, u, the
+  // U vector) through v_readlane.  The translation is branch-free: every lane evaluates
+  //     v + rA X1 - rB X2 - ( (X3 + rA X4 - rB X5) rG - (X6 + rA X7 - rB X8) rK )
+  // with per-lane source lanes and 0/1 masks fixed before the loop (B, B^T and p_a lanes use the first two terms only,
+  // C / p_l / idle lanes none), so one batch of 8 bpermutes and one wait serve the whole step.
+  {
+    const int l = w.lane(), i = l >> 3, j = l & 7;
+    const int ia = i < 3 ? i : (i < 6 ? i - 3 : 0), ja = j < 3 ? j : (j < 6 ? j - 3 : 0);
+    const int i1 = ia == 2 ? 0 : ia + 1, i2 = ia == 0 ? 2 : ia - 1, j1 = ja == 2 ? 0 : ja + 1, j2 = ja == 0 ? 2 : ja - 1;
+    const bool typeA = i < 3 && j < 3, typeB = i < 3 && j >= 3 && j < 6, typeBt = i >= 3 && i < 6 && j < 3, typeP = i < 3 && j == 6;
+    const int own_off = aba_own_word(i, j);
+    // first pair of terms: coefficient indices into r and source lanes
+    int kA = 0, kB = 0, s1 = l, s2 = l;
+    if (typeA) { kA = i1; kB = i2; s1 = 8 * j + 3 + i2; s2 = 8 * j + 3 + i1; }
+    else if (typeB) { kA = i1; kB = i2; s1 = 8 * (3 + i2) + j; s2 = 8 * (3 + i1) + j; }
+    else if (typeBt) { kA = j1; kB = j2; s1 = 8 * (3 + j2) + i; s2 = 8 * (3 + j1) + i; }
+    else if (typeP) { kA = i1; kB = i2; s1 = 8 * (3 + i2) + 6; s2 = 8 * (3 + i1) + 6; }
+    const real m1 = (typeA || typeB || typeBt || typeP) ? (real)1 : (real)0, m2 = typeA ? (real)1 : (real)0;
+    int s3 = l, s4 = l, s5 = l, s6 = l, s7 = l, s8 = l;
+    if (typeA) { s3 = 8 * i + 3 + j1; s4 = 8 * (3 + i2) + 3 + j1; s5 = 8 * (3 + i1) + 3 + j1; s6 = 8 * i + 3 + j2; s7 = 8 * (3 + i2) + 3 + j2; s8 = 8 * (3 + i1) + 3 + j2; }
+    const int sUj = j < 6 ? 8 * j : l;                                 // any lane of row j holds U_j
+    real carry = 0, hold = 0;
+    for (int L = NL - 1; L >= 0; L--) {
+      const int p = L_PARENT[L], jt = L_JTYPE[L];
+      const bool leaf = (L == NL - 1) || (L == ANL - 1) || (L == ANL - 2);
+      const real own = sh.a.IAP[L][own_off];
+      const real m = leaf ? own : own + carry;
+      if (jt == PIH_JT_FLOATING) {
+        w.sync(); if (l < 48) Mx[l] = m; w.sync();
+        aba_root_inverse(sh, Mx, rootp);
+        continue;
+      }
+      const int sb = jt == PIH_JT_REVOLUTE ? 0 : 3;
+      const V3 a = ld3(sh.LA[L]);
+      const real rA = m1 * sh.AR[L][kA], rB = m1 * sh.AR[L][kB], rG = m2 * sh.AR[L][j2], rK = m2 * sh.AR[L][j1];
+      const real cj = j < 6 ? sh.a.CB[L][j] : (real)0;
+      const int js = j - sb;
+      const real sj = js == 0 ? a.x : (js == 1 ? a.y : (js == 2 ? a.z : (real)0));
+      const real Ui = sum8(m * sj);                                    // U_i = sum_k I^A[i][sb + k] a_k, in every lane of row i
+      const real Uj = from_lane(Ui, 4 * sUj);
+      const real D = a.x * rdlane(Ui, 8 * sb) + a.y * rdlane(Ui, 8 * (sb + 1)) + a.z * rdlane(Ui, 8 * (sb + 2));
+      const real tau = -L_DAMPING[L] * sh.u[link_dof(L)];
+      const real u = tau - (a.x * rdlane(m, 8 * sb + 6) + a.y * rdlane(m, 8 * (sb + 1) + 6) + a.z * rdlane(m, 8 * (sb + 2) + 6));
+      const real Di = (real)1 / D;
+      if (j == 0 && i < 6) sh.AU[L][i] = Ui;
+      if (l == 0) { sh.ADinv[L] = Di; sh.Au[L] = u; }
+      if (p < 0) continue;   // arm root: parent is the fixed world
+      real ma = j < 6 ? m - Ui * Uj * Di : m;                          // I^a ; column 6 is fixed up next
+      const real s = sum8(j < 6 ? ma * cj : (real)0);                  // (I^a c)_i in every lane of row i
+      if (j == 6) ma = m + s + Ui * (u * Di);                          // p^a = p^A + I^a c + U u / D
+      const real X1 = from_lane(ma, 4 * s1), X2 = from_lane(ma, 4 * s2), X3 = from_lane(ma, 4 * s3), X4 = from_lane(ma, 4 * s4),
+                 X5 = from_lane(ma, 4 * s5), X6 = from_lane(ma, 4 * s6), X7 = from_lane(ma, 4 * s7), X8 = from_lane(ma, 4 * s8);
+      const real v = ma + rA * X1 - rB * X2 - ((X3 + rA * X4 - rB * X5) * rG - (X6 + rA * X7 - rB * X8) * rK);
+      if (L == ANL - 1) hold = v;                                      // finger 8: park until finger 7 is done
+      else if (L == ANL - 2) carry = v + hold;                         // finger 7: both fingers feed link 6
+      else carry = v;
+    }
+    w.sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ motor response rows
+// pull the 32 motor response rows out of their LDS staging words into registers (lane = DOF: arm lanes hold column d of the
+// 9 x 9 arm block, pipe lanes column d - 9 of the 23 x 29 pipe block) before the contact rows of the second pass overwrite them
+PIH_HD void pull_motor_rows(Wave& w, Shared& sh, MotorW& mw) {
+  const int d = w.lane();
+#pragma unroll
+  for (int j = 0; j < PIH_OBJ_NJ; j++) mw.w[j] = d < 9 ? (j < 9 ? wma_row(sh, j)[d] : (real)0) : (d < ND ? wmp_row(sh, j)[d - 9] : (real)0);
+}
+
+// ------------------------------------------------------------------------------------------------ PGS
+// after row16_sum3: rows 1,3 += lane 15 of the previous row (row_bcast:15), rows 2,3 += lane 31 (row_bcast:31)
+// => lanes 32..47 hold the sum over lanes 0..47 (all 38 DOF lanes).  Written as inline asm because hipcc lowers the
+// masked-row form to v_mov 0 + v_mov_dpp + v_add (3 instructions) instead of one fused v_add_f32_dpp; the s_nop covers the
+// VALU-write -> DPP-read hazard that the compiler does not pad inside asm.
+#ifndef PIH_DPP_ASM
+#define PIH_DPP_ASM 1
+#endif
+#if PIH_DPP_ASM
+PIH_HD void rows012_total3(real& a, real& b, real& c) {
+  __asm__ volatile("s_nop 1\n\t"
+                   "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\t"
+                   "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa\n\t"
+                   "s_nop 1\n\t"
+                   "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc\n\t"
+                   "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc\n\t"
+                   "s_nop 1"
+                   : "+v"(a), "+v"(b), "+v"(c));
+}
+#else
+template <int CTRL, int ROWMASK> PIH_HD real dpp_add_rows(real x) {
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, false));
+}
+PIH_HD void rows012_total3(real& a, real& b, real& c) {
+  a = dpp_add_rows<0x142, 0xA>(a); b = dpp_add_rows<0x142, 0xA>(b); c = dpp_add_rows<0x142, 0xA>(c);
+  a = dpp_add_rows<0x143, 0xC>(a); b = dpp_add_rows<0x143, 0xC>(b); c = dpp_add_rows<0x143, 0xC>(c);
+}
+#endif
+// after this every lane holds the sum over its 16-lane row; three independent reductions interleaved for ILP
+PIH_HD void row16_sum3(real& a, real& b, real& c) {
+  a = dpp_add<0xB1>(a); b = dpp_add<0xB1>(b); c = dpp_add<0xB1>(c);        // quad_perm [1,0,3,2]
+  a = dpp_add<0x4E>(a); b = dpp_add<0x4E>(b); c = dpp_add<0x4E>(c);        // quad_perm [2,3,0,1]
+  a = dpp_add<0x141>(a); b = dpp_add<0x141>(b); c = dpp_add<0x141>(c);     // row_half_mirror
+  a = dpp_add<0x140>(a); b = dpp_add<0x140>(b); c = dpp_add<0x140>(c);     // row_mirror
+}
+
+
+// Sequential impulse, Bullet resolveSingleConstraintRowGeneric form; row order: per arm joint (motor, lower limit, upper
+// limit), the 23 pipe motors, then per contact (normal, dir1, dir2).  Returns iterations executed.
+// GPU form: one lane per DOF holds its entry of the velocity change `du`; row multipliers live lane-distributed in
+// registers (v_readlane to broadcast); motor response rows are preloaded into registers; the arm and pipe motor chains
+// commute (disjoint DOFs) and are interleaved for ILP; each contact is solved as an exact 3x3 Gauss-Seidel block: three
+// DPP row-reductions in flight at once, then the cross terms G bring dir1/dir2 up to date without touching `du`.
+PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW& mw) {
+  const int nc = sh.nc;
+  // early exit test without divisions: (dl / dinv)^2 <= resid  <=>  dl^2 - resid dinv^2 <= 0  for every row
+  w.sync();
+  const int d = w.lane();
+  const DofGeom g = dof_geom(sh, d);
+  const bool armlane = d < 9;
+  const int dw = d < ND ? d : ND;   // response-row word of this lane (idle lanes read the zero pad)
+  // motor / limit multipliers: wave-uniform values held in VGPRs (no readlane, no conditional write-back);
+  // contact multipliers: lane-distributed, contact c in lane c
+  real lam_p[PIH_OBJ_NJ], lam_a[9], lam_lo[9], lam_hi[9];
+#pragma unroll
+  for (int j = 0; j < PIH_OBJ_NJ; j++) lam_p[j] = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
+  // per-lane sign of every contact's Jacobian column, 2 bits per contact (two's complement: 00 = 0, 01 = +1, 11 = -1, read
+  // back with one v_bfe_i32): +1 if this lane's joint is an ancestor of linkA, -1 of linkB, 0 of both or neither
+  unsigned sg0 = 0, sg1 = 0, sg2 = 0;
+  // Jacobian column of this lane for a point p: cross(ae, p - g.o) + mp  (revolute-like: ae = axis, mp = 0; prismatic-like:
+  // ae = 0, mp = axis; unused lane: both 0) -- no per-contact select
+  const V3 ae = g.kind == 0 ? g.a : mk(0, 0, 0), mp = g.kind == 1 ? g.a : mk(0, 0, 0);
+  real du = 0;
+  for (int c = 0; c < nc; c++) {
+    int la = sh.c_la[c], lb = sh.c_lb[c];
+    int sgn = g.kind != 2 ? (int)is_anc(g.L, la) - (int)is_anc(g.L, lb) : 0;
+    unsigned code = (unsigned)sgn & 3u;
+    if (c < 16) sg0 |= code << (2 * c); else if (c < 32) sg1 |= code << (2 * (c - 16)); else sg2 |= code << (2 * (c - 32));
+    real l = sh.r_lam[3 * c];   // warm start (uniform LDS read)
+    if (l != 0) {
+      du += (c < CL ? sh.b.Wp[3 * c][dw] : ov.base[(size_t)(3 * (c - CL)) * WPS + dw]) * l;
+    }
+  }
+  // one PGS iteration; returns true when every row moved by less than its threshold
+  auto iterate = [&]() __attribute__((always_inline)) -> bool {
+    // Early exit (Bullet's least-squares residual test, max over rows of (d lambda / dinv)^2 <= resid) as |d lambda| >
+    // sqrt(resid) dinv per row: one v_cmp into a wave mask + a scalar OR per row instead of an FMA and a max.  Bit 32 is read:
+    // the motor chain is wave-uniform and the contact chain is valid in lanes 32..47.
+    unsigned long long busy = 0;
+    // the row constants are re-read from LDS every iteration ON PURPOSE: without this compiler barrier LICM hoists all
+    // ~155 loop-invariant loads out of the iteration loop and spills them to scratch inside the hot loop
+    __asm__ volatile("" ::: "memory");
+    // row constants come from LDS as 16-byte broadcasts, explicitly prefetched PF records ahead: the dependent chain of one
+    // motor step is ~6 VALU ops (~50 cycles) while an LDS round trip is >100, so a distance-1 prefetch stalls every step
+    constexpr int PF = 6;
+    real4 pm[PF], pa4[PF], pl4[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) { pm[k] = *reinterpret_cast<const real4*>(sh.mrec[9 + k]); pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
+#pragma unroll
+    for (int j = 0; j < PIH_OBJ_NJ; j++) {
+      real tot_a = 0;
+      const real4 cm = pm[j % PF];
+      if (j + PF < PIH_OBJ_NJ) pm[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[9 + j + PF]);
+      if (j < 9) {   // arm joint block: motor, lower limit, upper limit (wave-uniform chain)
+        const real4 ca = pa4[j % PF], cl = pl4[j % PF];
+        if (j + PF < 9) { pa4[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[j + PF]); pl4[j % PF] = *reinterpret_cast<const real4*>(sh.lrec[j + PF]); }
+        const real di = ca.x, rhs = ca.y, thr = ca.z, lim = ca.w;
+        const real lor = cl.x, hir = cl.y, wjj = cl.z;
+        real dj = rdlane(du, j);
+        real sum = lam_a[j] + (rhs - dj * di);
+        sum = med3_(sum, -lim, lim);
+        real dl = sum - lam_a[j]; lam_a[j] = sum;
+        busy |= __ballot(absr(dl) > thr);
+        dj += dl * wjj;
+        real s2 = lam_lo[j] + (lor - dj * di); s2 = max_(s2, (real)0);
+        real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
+        busy |= __ballot(absr(d2) > thr);
+        dj += d2 * wjj;
+        real s3 = lam_hi[j] + (hir + dj * di); s3 = max_(s3, (real)0);
+        real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
+        busy |= __ballot(absr(d3) > thr);
+        tot_a = dl + d2 - d3;
+      }
+      // pipe joint motor j (DOF 15 + j)
+      const real di = cm.x, rhs = cm.y, thr = cm.z, lim = cm.w;
+      real dj = rdlane(du, 15 + j);
+      real sum = lam_p[j] + (rhs - dj * di);
+      sum = med3_(sum, -lim, lim);
+      real dl = sum - lam_p[j]; lam_p[j] = sum;
+      busy |= __ballot(absr(dl) > thr);
+      du += mw.w[j] * (armlane ? tot_a : dl);
+    }
+    // one exact 3x3 Gauss-Seidel block per contact.  The body is instantiated twice so that the LDS-resident contacts
+    // (c < CL) compile to ds_read with immediate offsets and only the rare spilled ones (c >= CL) use global loads; a
+    // single loop over "LDS or global" pointers degrades every access to flat_load + vmcnt(0)/lgkmcnt(0) waits.
+    // Whole record (8 x 16 B) + the three response-row entries of this lane are fetched in ONE batch, and for the
+    // LDS-resident contacts the next contact's batch is issued before the current block computes (software pipelining):
+    // piecemeal loads cost four serial LDS round trips per contact, which two waves per SIMD cannot hide.
+    struct CRec { real4 q[8]; real w0, w1, w2; };
+    auto fetch = [&](const real* R, const real* wr) __attribute__((always_inline)) -> CRec {
+      CRec r;
+#pragma unroll
+      for (int i = 0; i < 8; i++) r.q[i] = reinterpret_cast<const real4*>(R)[i];
+      r.w0 = wr[dw]; r.w1 = wr[WPS + dw]; r.w2 = wr[2 * WPS + dw];
+      return r;
+    };
+    auto block = [&](int c, unsigned sgw, const CRec& r, real* R, bool in_lds) __attribute__((always_inline)) {
+      // q0 = p.xyz, lo_n | q1 = hi_floor, mu, -, - | q2 = n, dinv_n | q3 = t1, dinv_t1 | q4 = t2, dinv_t2
+      // q5 = rhs n,t1,t2, G[t1][n] | q6 = G[t2][n], G[t2][t1], lam_n, lam_t1 | q7 = lam_t2, ...
+      // (lo_n = 0 / -BIG and hi_floor = 0 / +BIG make the attach rows bilateral without a select)
+      const real w0 = r.w0, w1 = r.w1, w2 = r.w2;
+      const V3 pr = mk(r.q[0].x - g.o.x, r.q[0].y - g.o.y, r.q[0].z - g.o.z);
+      const real mu = r.q[1].y;
+      const real sdu = (real)(int)__builtin_amdgcn_sbfe(sgw, 2u * (unsigned)(c & 15), 2u) * du;
+      const V3 cv = mk(__builtin_fmaf(ae.y, pr.z, __builtin_fmaf(-ae.z, pr.y, mp.x)), __builtin_fmaf(ae.z, pr.x, __builtin_fmaf(-ae.x, pr.z, mp.y)), __builtin_fmaf(ae.x, pr.y, __builtin_fmaf(-ae.y, pr.x, mp.z)));
+      real jd0 = sdu * dot(mk(r.q[2].x, r.q[2].y, r.q[2].z), cv), jd1 = sdu * dot(mk(r.q[3].x, r.q[3].y, r.q[3].z), cv), jd2 = sdu * dot(mk(r.q[4].x, r.q[4].y, r.q[4].z), cv);
+      // materialise the products: otherwise fast-math folds the multiply into the first reduction step as mul + mov_dpp + fmac
+      // (3 instructions per value) instead of mul + v_add_f32_dpp (2)
+      __asm__ volatile("" : "+v"(jd0), "+v"(jd1), "+v"(jd2));
+      row16_sum3(jd0, jd1, jd2);
+      rows012_total3(jd0, jd1, jd2);          // valid in lanes 32..47 from here; the scalar chain below runs in plain VGPRs
+      const real l0 = r.q[6].z, l1 = r.q[6].w, l2 = r.q[7].x;
+      const real di0 = r.q[2].w, di1 = r.q[3].w, di2 = r.q[4].w;
+      real s0 = l0 + (r.q[5].x - jd0 * di0);
+      s0 = max_(s0, r.q[0].w);
+      real dl0 = s0 - l0;
+      busy |= __ballot(absr(dl0) > r.q[7].y);
+      real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
+      if (rdlane(s0, 32) > 0 || rdlane(mu, 32) < 0) {   // wave-uniform branch (Bullet skips the friction rows of an unloaded contact)
+        real hi = max_(mu * s0, r.q[1].x);
+        jd1 += r.q[5].w * dl0;
+        s1 = l1 + (r.q[5].y - jd1 * di1); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
+        busy |= __ballot(absr(dl1) > r.q[7].z);
+        jd2 += r.q[6].x * dl0 + r.q[6].y * dl1;
+        s2 = l2 + (r.q[5].z - jd2 * di2); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
+        busy |= __ballot(absr(dl2) > r.q[7].w);
+      }
+      if (d == 32) { R[26] = s0; R[27] = s1; R[28] = s2; }
+      if (!in_lds) __threadfence_block();     // spilled records live in global memory: make lane 32's store visible to the wave
+      du += w0 * rdlane(dl0, 32) + w1 * rdlane(dl1, 32) + w2 * rdlane(dl2, 32);
+    };
+    const int ncl = nc < CL ? nc : CL;
+    if (ncl > 0) {
+      // two-deep ping-pong (ra / rb) instead of "cur = nxt": the rotation of a 27-register record costs 27 v_mov per contact
+      CRec ra = fetch(sh.b.crec[0], &sh.b.Wp[0][0]);
+      int c = 0;
+      for (;;) {
+        const int c1 = c + 1 < ncl ? c + 1 : c;
+        CRec rb = fetch(sh.b.crec[c1], &sh.b.Wp[3 * c1][0]);
+        block(c, c < 16 ? sg0 : sg1, ra, sh.b.crec[c], true);
+        if (++c >= ncl) break;
+        const int c2 = c + 1 < ncl ? c + 1 : c;
+        ra = fetch(sh.b.crec[c2], &sh.b.Wp[3 * c2][0]);
+        block(c, c < 16 ? sg0 : sg1, rb, sh.b.crec[c], true);
+        if (++c >= ncl) break;
+      }
+    }
+    if (nc > CL) {
+      // the spilled contacts (global scratch) with the same one-ahead ping-pong: an env that gets here is one of the heaviest of
+      // the launch, i.e. the one the launch ends up waiting for, and an unprefetched global load per contact is its latency
+      auto rec_of = [&](int c) { return ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC; };
+      auto row_of = [&](int c) { return ov.base + (size_t)(3 * (c - CL)) * WPS; };
+      CRec ra = fetch(rec_of(CL), row_of(CL));
+      int c = CL;
+      for (;;) {
+        const int c1 = c + 1 < nc ? c + 1 : c;
+        CRec rb = fetch(rec_of(c1), row_of(c1));
+        block(c, c < 32 ? sg1 : sg2, ra, rec_of(c), false);
+        if (++c >= nc) break;
+        const int c2 = c + 1 < nc ? c + 1 : c;
+        ra = fetch(rec_of(c2), row_of(c2));
+        block(c, c < 32 ? sg1 : sg2, rb, rec_of(c), false);
+        if (++c >= nc) break;
+      }
+    }
+    return !((busy >> 32) & 1ull);
+  };
+  // the body is instantiated twice per trip: the multipliers are loop-carried, and with a single copy every new value has
+  // to be moved back into the register the loop header expects (~50 v_mov per iteration)
+  int it = 0;
+  while (it < P.iters) {
+    it++; if (iterate()) break;
+    if (it >= P.iters) break;
+    it++; if (iterate()) break;
+  }
+  w.sync();
+  if (d < nc) { const real* R = d < CL ? sh.b.crec[d] : ov.base + OVF_W_WORDS + (size_t)(d - CL) * CREC; sh.r_lam[3 * d] = R[26]; sh.r_lam[3 * d + 1] = R[27]; sh.r_lam[3 * d + 2] = R[28]; }
+  if (d < ND) sh.u[d] += du;
+  w.sync();
+  return it;
+}
+
+}  // namespace pih

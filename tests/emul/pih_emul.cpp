@@ -1,9 +1,10 @@
-// pih_emul.cpp -- TEST-ONLY host build of the product's per-env step (peg_in_hole_gym_amd/csrc/pih_device.h compiled
-// with PIH_HOST_EMUL: lanes become loops).  It exists so that the device algorithm (ABA + impulse responses + PGS with
+// pih_emul.cpp -- TEST-ONLY host build of the product's per-env step (csrc/pih_common.h + pih_step.h instantiated with the host
+// wave layer of this directory: lanes become loops).  It exists so that the device algorithm (ABA + impulse responses + PGS with
 // on-the-fly Jacobians) can be checked against the fp64 oracle in this GPU-less container, in double (algorithmic
 // equivalence) and in float (fp32 sensitivity).  It is NOT part of the product: libpih_hip.so contains no host path.
-#define PIH_HOST_EMUL 1
-#include "../../peg_in_hole_gym_amd/csrc/pih_device.h"
+#include "pih_host_platform.h"                              // real, PIH_HD, ... for the host (before any product header)
+#include "pih_wave_host.h"                                  // host wave layer (+ the product's pih_common.h)
+#include "../../peg_in_hole_gym_amd/csrc/pih_step.h"        // the product's step, instantiated with the host wave layer
 #include "../../peg_in_hole_gym_amd/csrc/pih_fly.h"
 #include <cstdlib>
 #include <cstring>

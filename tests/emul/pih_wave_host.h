@@ -1,0 +1,207 @@
+// pih_wave_host.h -- TEST-ONLY host implementation of the wave layer (the product's is csrc/pih_wave.h, gfx950 only): lanes
+// become loops, the scans become serial recursions, the entry-parallel ABA sweep runs through three 48-word arrays, and PGS is
+// the plain row-by-row form.  With it tests/emul compiles the product's pih_common.h / pih_step.h for the host so that the
+// device ALGORITHM (ABA + impulse responses + on-the-fly Jacobians) can be checked against the fp64 oracle without a GPU.
+#pragma once
+#include "../../peg_in_hole_gym_amd/csrc/pih_common.h"
+
+namespace pih {
+
+struct Wave {
+  static constexpr bool controller_inline = true;      // no pre-kernel on the host: the controller runs inside step_env
+  real Tl[NL][12];                                      // local (parent->link) transforms
+  real du[ND];
+  real hWmp[PIH_OBJ_NJ][WMS], hWma[9][9];               // motor response rows (the GPU keeps them in registers)
+  void stamp(int) {}
+  void phase_begin() {}
+  void phase(int) {}
+  int lane() const { return 0; }
+  void sync() {}
+  template <class F> void par(int n, F f) { for (int i = 0; i < n; i++) f(i); }
+  // deterministic stream compaction: returns the slot of item i if valid (items are visited in index order)
+  int counter = 0;
+  int alloc(bool valid) { return valid ? counter++ : -1; }
+  void alloc_reset(int base) { counter = base; }
+  int alloc_count() const { return counter; }
+  template <class F> void par_all(int n, F f) { for (int i = 0; i < n; i++) f(i, true); }
+};
+PIH_HD void fk_all(Wave& w, Shared& sh) {
+  w.par(NL, [&](int L) {
+    real q = L < ANL ? sh.S[PIH_S_QARM + L] : (L == ANL ? (real)0 : sh.S[PIH_S_QJ + L - ANL - 1]);
+    local_transform(L, q, sh.S, w.Tl[L]);
+  });
+  // serial composition down the two chains (wave-uniform).  The parent's pose is carried in registers (no LDS read-back
+  // on the dependency chain); link 6's pose is kept for the second finger (link 8, whose parent is 6, not 7).
+  {
+    M3 Rp = ldm(ARM_BASE_R), R6 = Rp; V3 op = mk(0, 0, 0), o6 = op;
+    for (int L = 0; L < NL; L++) {
+      M3 Tl = ldm(w.Tl[L]); V3 tl = ld3(w.Tl[L] + 9);
+      M3 R; V3 o;
+      if (L_JTYPE[L] == PIH_JT_FLOATING) { R = Tl; o = tl; }
+      else {
+        if (L == ANL - 1) { Rp = R6; op = o6; }
+        R = mul(Rp, Tl); o = op + mul(Rp, tl);
+      }
+      stm(sh.a.LR[L], R); st3(sh.LO[L], o);
+      Rp = R; op = o;
+      if (L == ANL - 3) { R6 = R; o6 = o; }
+    }
+  }
+  w.par(NL, [&](int L) {
+    M3 R = ldm(sh.a.LR[L]);
+    st3(sh.LA[L], mul(R, ld3(L_AXIS[L])));
+    st3(sh.a.LRC[L], mul(R, ld3(L_COM[L])));
+    sts3(sh.a.LIC[L], rot_sym(R, lds3(L_INERTIA[L])));
+  });
+}
+// link velocities from the generalized velocity sh.u (wave-uniform serial sweep)
+PIH_HD void link_velocities_serial(Shared& sh) {
+  V3 wp = mk(0, 0, 0), vp = mk(0, 0, 0), op = mk(0, 0, 0), w6 = wp, v6 = vp, o6 = op;   // parent's twist / origin, in registers
+  for (int L = 0; L < NL; L++) {
+    int jt = L_JTYPE[L], d = link_dof(L);
+    V3 wv, vv, o = ld3(sh.LO[L]);
+    if (jt == PIH_JT_FLOATING) { vv = ld3(&sh.u[d]); wv = ld3(&sh.u[d + 3]); }
+    else {
+      if (L == ANL - 1) { wp = w6; vp = v6; op = o6; }
+      V3 vat = L == 0 ? mk(0, 0, 0) : vp + cross(wp, o - op);
+      if (L == 0) wp = mk(0, 0, 0);
+      V3 aq = sh.u[d] * ld3(sh.LA[L]);
+      if (jt == PIH_JT_REVOLUTE) { wv = wp + aq; vv = vat; } else { wv = wp; vv = vat + aq; }
+    }
+    st3(sh.VW[L], wv); st3(sh.VV[L], vv);
+    wp = wv; vp = vv; op = o;
+    if (L == ANL - 3) { w6 = wv; v6 = vv; o6 = o; }
+  }
+}
+PIH_HD void link_velocities(Wave& w, Shared& sh) { (void)w; link_velocities_serial(sh); }
+
+// inward sweep of the articulated-body algorithm, the same four lane-parallel steps per link as the GPU form, through three
+// 48-word arrays (Mx = running I^A, Cy = I^a of this link, Hd = the parked second finger; they alias r_lam)
+PIH_HD void aba_inward(Wave& w, Shared& sh, areal* rootp) {
+  real* const Mx = sh.r_lam; real* const Cy = sh.r_lam + 48; real* const Hd = sh.r_lam + 96; real* const Uv = sh.udot;
+  for (int L = NL - 1; L >= 0; L--) {
+    const int p = L_PARENT[L], jt = L_JTYPE[L];
+    const bool leaf = (L == NL - 1) || (L == ANL - 1) || (L == ANL - 2);
+    w.par(48, [&](int l) {
+      const real own = sh.a.IAP[L][aba_own_word(l >> 3, l & 7)];
+      Mx[l] = leaf ? own : own + Mx[l];
+    });
+    if (jt == PIH_JT_FLOATING) { aba_root_inverse(sh, Mx, rootp); continue; }
+    const int sb = jt == PIH_JT_REVOLUTE ? 0 : 3;
+    const V3 a = ld3(sh.LA[L]);
+    w.par(6, [&](int i) { Uv[i] = Mx[8 * i + sb] * a.x + Mx[8 * i + sb + 1] * a.y + Mx[8 * i + sb + 2] * a.z; });
+    const real tau = -L_DAMPING[L] * sh.u[link_dof(L)];
+    const real D = a.x * Uv[sb] + a.y * Uv[sb + 1] + a.z * Uv[sb + 2];
+    const real u = tau - (a.x * Mx[8 * sb + 6] + a.y * Mx[8 * (sb + 1) + 6] + a.z * Mx[8 * (sb + 2) + 6]);
+    const real Di = (real)1 / D;
+    w.par(6, [&](int i) { sh.AU[L][i] = Uv[i]; });
+    sh.ADinv[L] = Di; sh.Au[L] = u;
+    if (p < 0) continue;   // arm root: parent is the fixed world
+    const real ud = u * Di;
+    w.par(48, [&](int l) {
+      const int i = l >> 3, j = l & 7;
+      real v = 0;
+      if (j < 6) v = Mx[l] - Uv[i] * Uv[j] * Di;
+      else if (j == 6) {
+        real s1 = 0;
+        for (int k = 0; k < 6; k++) s1 += (Mx[8 * i + k] - Uv[i] * Uv[k] * Di) * sh.a.CB[L][k];
+        v = Mx[l] + s1 + Uv[i] * ud;                                   // p + I^a c + U u / D
+      }
+      Cy[l] = v;
+    });
+    w.par(48, [&](int l) {
+      const int i = l >> 3, j = l & 7;
+      const int ia = i < 3 ? i : i - 3, ja = j < 3 ? j : j - 3;
+      const int i1 = ia == 2 ? 0 : ia + 1, i2 = ia == 0 ? 2 : ia - 1, j1 = ja == 2 ? 0 : ja + 1, j2 = ja == 0 ? 2 : ja - 1;
+      const real* r = sh.AR[L];
+      real v = Cy[l];
+      if (j < 6) {
+        if (i < 3 && j >= 3) v += r[i1] * Cy[8 * (3 + i2) + j] - r[i2] * Cy[8 * (3 + i1) + j];                    // B'[i][j-3]
+        else if (i >= 3 && j < 3) v += r[j1] * Cy[8 * (3 + j2) + i] - r[j2] * Cy[8 * (3 + j1) + i];               // B'[j][i-3] (C symmetric)
+        else if (i < 3 && j < 3) {
+          v += r[i1] * Cy[8 * j + 3 + i2] - r[i2] * Cy[8 * j + 3 + i1];                                           // ([r]x B^T)[i][j], B^T[k][j] = B[j][k]
+          const real b1 = Cy[8 * i + 3 + j1] + r[i1] * Cy[8 * (3 + i2) + 3 + j1] - r[i2] * Cy[8 * (3 + i1) + 3 + j1];   // B'[i][j1]
+          const real b2 = Cy[8 * i + 3 + j2] + r[i1] * Cy[8 * (3 + i2) + 3 + j2] - r[i2] * Cy[8 * (3 + i1) + 3 + j2];   // B'[i][j2]
+          v -= b1 * r[j2] - b2 * r[j1];                                                                          // (B' [r]x)[i][j]
+        }
+      } else if (j == 6 && i < 3) v += r[i1] * Cy[8 * (3 + i2) + 6] - r[i2] * Cy[8 * (3 + i1) + 6];               // p_a + r x p_l
+      if (L == ANL - 1) Hd[l] = v;                                    // finger 8: park until finger 7 is done
+      else if (L == ANL - 2) Mx[l] = v + Hd[l];                       // finger 7: both fingers feed link 6
+      else Mx[l] = v;
+    });
+  }
+}
+
+PIH_HD void pull_motor_rows(Wave& w, Shared& sh, MotorW& mw) {
+  for (int j = 0; j < PIH_OBJ_NJ; j++) for (int k = 0; k < 29; k++) w.hWmp[j][k] = wmp_row(sh, j)[k];
+  for (int j = 0; j < 9; j++) for (int k = 0; k < 9; k++) w.hWma[j][k] = wma_row(sh, j)[k];
+  (void)mw;
+}
+
+// Sequential impulse, Bullet resolveSingleConstraintRowGeneric form; row order: per arm joint (motor, lower limit, upper
+// limit), the 23 pipe motors, then per contact (normal, dir1, dir2).  Returns iterations executed.
+// GPU form: one lane per DOF holds its entry of the velocity change `du`; row multipliers live lane-distributed in
+// registers (v_readlane to broadcast); motor response rows are preloaded into registers; the arm and pipe motor chains
+// commute (disjoint DOFs) and are interleaved for ILP; each contact is solved as an exact 3x3 Gauss-Seidel block: three
+// DPP row-reductions in flight at once, then the cross terms G bring dir1/dir2 up to date without touching `du`.
+PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW& mw) {
+  const int nc = sh.nc;
+  // early exit test without divisions: (dl / dinv)^2 <= resid  <=>  dl^2 - resid dinv^2 <= 0  for every row
+  real* du = w.du;
+  for (int d = 0; d < ND; d++) du[d] = 0;
+  DofGeom geo[ND];
+  for (int d = 0; d < ND; d++) geo[d] = dof_geom(sh, d);
+  auto Wrow = [&](int row, int d) -> real {   // contact-row response entry for dof d
+    return wp_row(sh, ov, row)[d];
+  };
+  for (int c = 0; c < nc; c++) { real l = sh.r_lam[3 * c]; if (l != 0) for (int d = 0; d < ND; d++) du[d] += Wrow(3 * c, d) * l; }
+  real mlam[NMOT], llam[NLIM];
+  for (int m = 0; m < NMOT; m++) mlam[m] = 0;
+  for (int k = 0; k < NLIM; k++) llam[k] = 0;
+  int it = 0;
+  for (; it < P.iters; it++) {
+    real worst = -1;
+    auto track = [&](real dl, real di) { real v = dl * dl - P.resid * di * di; if (v > worst) worst = v; };
+    for (int m = 0; m < NMOT; m++) {
+      int d = m < 9 ? m : 15 + (m - 9);
+      real dl = sh.mrec[m][1] - du[d] * sh.mrec[m][0], sum = mlam[m] + dl, lim = sh.mrec[m][3];
+      if (sum < -lim) { dl = -lim - mlam[m]; sum = -lim; } else if (sum > lim) { dl = lim - mlam[m]; sum = lim; }
+      mlam[m] = sum;
+      if (m < 9) for (int k = 0; k < 9; k++) du[k] += w.hWma[m][k] * dl; else for (int k = 0; k < 29; k++) du[9 + k] += w.hWmp[m - 9][k] * dl;
+      track(dl, sh.mrec[m][0]);
+      if (m < 9) for (int side = 0; side < 2; side++) {   // the joint's lower / upper limit rows follow its motor row
+        int k = 2 * m + side; real sg = side ? (real)-1 : (real)1;
+        real dl2 = sh.lrec[m][side] - sg * du[m] * sh.mrec[m][0], sum2 = llam[k] + dl2;
+        if (sum2 < 0) { dl2 = -llam[k]; sum2 = 0; }
+        llam[k] = sum2;
+        for (int j = 0; j < 9; j++) du[j] += sg * w.hWma[m][j] * dl2;
+        track(dl2, sh.mrec[m][0]);
+      }
+    }
+    for (int c = 0; c < nc; c++) {
+      const real* R = crec_of(sh, ov, c);
+      V3 p = ld3(R);
+      for (int k = 0; k < 3; k++) {
+        int row = 3 * c + k;
+        real lo = 0, hi = PIH_BIG;
+        if (R[5] < 0) lo = -PIH_BIG;                                   // bilateral (attach) rows
+        else if (k > 0) { real tot = sh.r_lam[3 * c]; if (!(tot > 0)) continue; hi = R[5] * tot; lo = -hi; }
+        V3 dir = ld3(R + 8 + 4 * k);
+        real jd = 0;
+        for (int d = 0; d < ND; d++) jd += jac_entry(geo[d], sh.c_la[c], sh.c_lb[c], p, dir) * du[d];
+        real di = R[11 + 4 * k];
+        real dl = R[20 + k] - jd * di, sum = sh.r_lam[row] + dl;
+        if (sum < lo) { dl = lo - sh.r_lam[row]; sum = lo; } else if (sum > hi) { dl = hi - sh.r_lam[row]; sum = hi; }
+        sh.r_lam[row] = sum;
+        for (int d = 0; d < ND; d++) du[d] += Wrow(row, d) * dl;
+        track(dl, di);
+      }
+    }
+    if (worst <= 0) { it++; break; }
+  }
+  for (int d = 0; d < ND; d++) sh.u[d] += du[d];
+  (void)mw;
+  return it;
+}
+
+}  // namespace pih

@@ -67,7 +67,7 @@ def test_non_finite_env_is_frozen_and_flagged(torch_mod):
     torch = torch_mod
     n = 8
     g = _gpu(n, seed=1)
-    s = g.state().clone(); s[2, 18] = float("nan"); s[5, 54] = float("nan"); g.set_state(s)
+    s = g.state().clone(); s[2, 18] = float("nan"); s[5, 31] = float("nan"); g.set_state(s)
     a = torch.zeros(n, 4, device="cuda")
     _, _, done = g.step(a)
     st = g.state()

@@ -7,7 +7,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 if [ "${2:-tests}" = "tests" ]; then
-  timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > $O/gpu_tests_$TAG.log 2>&1 || { echo "GPU TESTS FAILED"; tail -30 $O/gpu_tests_$TAG.log; exit 1; }
+  timeout -k 10 900 python -m pytest tests -m gpu -q -s > $O/gpu_tests_$TAG.log 2>&1 || { echo "GPU TESTS FAILED"; grep -E "^(FAILED|ERROR)|Error" $O/gpu_tests_$TAG.log | head -40; }
   tail -3 $O/gpu_tests_$TAG.log
 fi
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_driver.json 2> $O/bench_${TAG}_driver.err || { echo "BENCH FAILED"; tail -20 $O/bench_${TAG}_driver.err; exit 1; }
