@@ -256,6 +256,199 @@ PIH_HD void row16_sum3(real& a, real& b, real& c) {
 }
 
 
+// ---- PGS in ROW space for envs with few contacts (the common case: 80 % of the env-steps of the benchmark workload)
+// When all rows fit one wavefront -- 32 motor rows + 3 x (<= MERGED_CONTACTS) contact rows <= 62 -- lane g owns row g and holds
+//   v = J_g . du            the velocity change along its own row caused by every impulse applied so far, and
+//   A[i] = J_g . W_i        the response of its row to a unit impulse of row i, for EVERY row i (62 registers: the lane's row of the
+//                           Delassus matrix J M^-1 J^T, built once per step from the response rows that build_rows staged in LDS).
+// A row update then needs no Jacobian and no cross-lane reduction at all: one v_readlane (v of the row), the clamp chain in
+// wave-uniform VGPRs, and ONE FMA per row (v += A[i] * d lambda) -- 3 readlane + ~20 + 3 FMA per contact instead of the 87
+// instructions of the DOF-space block (on-the-fly Jacobian columns + three 38-lane DPP reductions), with the same sequence of
+// row updates as Bullet (per arm joint: motor, lower, upper limit; the 23 pipe motors; per contact: normal, dir1, dir2).  The DOF
+// velocities are recovered at the end as du = sum_i W_i lambda_i.  The arm-row and pipe-row columns are disjoint (A[arm][pipe
+// motor] = 0), so the motor chain runs on two accumulators for ILP exactly like the DOF-space chain.
+constexpr int FR = NMOT + 3 * MERGED_CONTACTS;
+PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
+  const int nc = __builtin_amdgcn_readfirstlane(sh.nc);
+  w.sync();
+  const int lane = w.lane();
+  // ---- this lane's Jacobian row (38 entries, registers): unit vector for a motor row, point Jacobian for a contact row
+  real J[ND];
+  {
+    const bool ismotor = lane < NMOT;
+    const int row = ismotor ? 0 : lane - NMOT, c = row / 3, k = row - 3 * c;
+    const bool live = !ismotor && c < nc;
+    int la = -1, lb = -1; V3 p = mk(0, 0, 0), dir = mk(0, 0, 0);
+    if (live) { la = sh.c_la[c]; lb = sh.c_lb[c]; const real* R = sh.b.crec[c]; p = ld3(R); dir = ld3(R + 8 + 4 * k); }
+    const int md = lane < 9 ? lane : 15 + (lane - 9);
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+      const DofGeom g = dof_geom(sh, d);
+      const real jc = live ? jac_entry(g, la, lb, p, dir) : (real)0;
+      J[d] = ismotor ? (d == md ? (real)1 : (real)0) : jc;
+      __asm__ volatile("" : "+v"(J[d]) :: "memory");     // one DOF at a time (same reason as for the columns of A below)
+    }
+  }
+  // ---- this lane's row of A: response rows broadcast from LDS (arm motor rows touch the 9 arm DOFs only, pipe motor rows the 29
+  // pipe DOFs only)
+  real A[FR];
+#pragma unroll
+  for (int g = 0; g < 9; g++) {
+    const real* wr = wma_row(sh, g); real a = 0;
+#pragma unroll
+    for (int d = 0; d < 9; d++) a += J[d] * wr[d];
+    // one column at a time: pin the sum HERE (an empty asm that "rewrites" it), otherwise the scheduler issues the LDS loads of all
+    // 62 columns first, spills them, and sinks the FMAs down to the first use of A
+    __asm__ volatile("" : "+v"(a) :: "memory");
+    A[g] = a;
+  }
+#pragma unroll
+  for (int g = 0; g < PIH_OBJ_NJ; g++) {
+    const real* wr = wmp_row(sh, g); real a = 0;
+#pragma unroll
+    for (int d = 9; d < ND; d++) a += J[d] * wr[d - 9];
+    __asm__ volatile("" : "+v"(a) :: "memory");
+    A[9 + g] = a;
+  }
+#pragma unroll
+  for (int c = 0; c < MERGED_CONTACTS; c++) {
+    if (c < nc) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const real* wr = sh.b.Wp[3 * c + k]; real a = 0;
+#pragma unroll
+        for (int d = 0; d < ND; d++) a += J[d] * wr[d];
+        __asm__ volatile("" : "+v"(a) :: "memory");
+        A[NMOT + 3 * c + k] = a;
+      }
+    } else { A[NMOT + 3 * c] = 0; A[NMOT + 3 * c + 1] = 0; A[NMOT + 3 * c + 2] = 0; }
+  }
+  // ---- pack the per-contact solver constants (16 words, read as 4 x b128 broadcasts per iteration) over the first half of the
+  // contact record, whose geometry is no longer needed:
+  //   0 rhs_n  1 rhs_t1  2 rhs_t2  3 G[t1][n] | 4 G[t2][n]  5 G[t2][t1]  6 mu  7 lo_n | 8 hi_floor  9 dinv_n  10 dinv_t1  11 dinv_t2 |
+  //   12 thr_n  13 thr_t1  14 thr_t2  15 - | 16 lambda_n  17 lambda_t1  18 lambda_t2 (running multipliers, rewritten by lane 0)
+  w.sync();
+  if (lane < nc) {
+    real* R = sh.b.crec[lane];
+    const real r0 = R[20], r1 = R[21], r2 = R[22], g10 = R[23], g20 = R[24], g21 = R[25], mu = R[5], lon = R[3], hif = R[4];
+    const real d0 = R[11], d1 = R[15], d2 = R[19], t0 = R[29], t1 = R[30], t2 = R[31];
+    R[0] = r0; R[1] = r1; R[2] = r2; R[3] = g10; R[4] = g20; R[5] = g21; R[6] = mu; R[7] = lon;
+    R[8] = hif; R[9] = d0; R[10] = d1; R[11] = d2; R[12] = t0; R[13] = t1; R[14] = t2; R[15] = 0;
+    R[16] = sh.r_lam[3 * lane]; R[17] = 0; R[18] = 0; R[19] = 0;      // warm start
+  }
+  w.sync();
+  // ---- multipliers: wave-uniform values in VGPRs
+  real lam_p[PIH_OBJ_NJ], lam_a[9], lam_lo[9], lam_hi[9];
+#pragma unroll
+  for (int j = 0; j < PIH_OBJ_NJ; j++) lam_p[j] = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
+  real v = 0;
+#pragma unroll
+  for (int c = 0; c < MERGED_CONTACTS; c++)
+    if (c < nc) v += A[NMOT + 3 * c] * sh.r_lam[3 * c];   // warm start
+  auto iterate = [&]() __attribute__((always_inline)) -> bool {
+    unsigned long long busy = 0;
+    __asm__ volatile("" ::: "memory");      // keep the row constants in LDS (see pgs(): LICM would hoist and spill them)
+    constexpr int PF = 4;
+    real4 pm[PF], pa4[PF], pl4[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) { pm[k] = *reinterpret_cast<const real4*>(sh.mrec[9 + k]); pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
+    // the arm rows and the pipe motor rows do not see each other (A[arm row][pipe motor row] = 0): two accumulators, two chains
+    real va = v, vp = v;
+#pragma unroll
+    for (int j = 0; j < PIH_OBJ_NJ; j++) {
+      const real4 cm = pm[j % PF];
+      if (j + PF < PIH_OBJ_NJ) pm[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[9 + j + PF]);
+      if (j < 9) {   // arm joint block: motor, lower limit, upper limit
+        const real4 ca = pa4[j % PF], cl = pl4[j % PF];
+        if (j + PF < 9) { pa4[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[j + PF]); pl4[j % PF] = *reinterpret_cast<const real4*>(sh.lrec[j + PF]); }
+        const real di = ca.x, rhs = ca.y, thr = ca.z, lim = ca.w;
+        const real lor = cl.x, hir = cl.y, wjj = cl.z;
+        real dj = rdlane(va, j);
+        real sum = lam_a[j] + (rhs - dj * di);
+        sum = med3_(sum, -lim, lim);
+        const real dl = sum - lam_a[j]; lam_a[j] = sum;
+        busy |= __ballot(absr(dl) > thr);
+        dj += dl * wjj;
+        real s2 = lam_lo[j] + (lor - dj * di); s2 = max_(s2, (real)0);
+        const real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
+        busy |= __ballot(absr(d2) > thr);
+        dj += d2 * wjj;
+        real s3 = lam_hi[j] + (hir + dj * di); s3 = max_(s3, (real)0);
+        const real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
+        busy |= __ballot(absr(d3) > thr);
+        va += A[j] * (dl + d2 - d3);
+      }
+      const real di = cm.x, rhs = cm.y, thr = cm.z, lim = cm.w;
+      const real dj = rdlane(vp, 9 + j);
+      real sum = lam_p[j] + (rhs - dj * di);
+      sum = med3_(sum, -lim, lim);
+      const real dl = sum - lam_p[j]; lam_p[j] = sum;
+      busy |= __ballot(absr(dl) > thr);
+      vp += A[9 + j] * dl;
+    }
+    v = (va + vp) - v;
+    // contacts: exact 3x3 Gauss-Seidel block in row space
+#pragma unroll
+    for (int c = 0; c < MERGED_CONTACTS; c++) {
+      if (c < nc) {
+        real* Rw = sh.b.crec[c];
+        const real4* R = reinterpret_cast<const real4*>(Rw);
+        const real4 q0 = R[0], q1 = R[1], q2 = R[2], q3 = R[3], q4 = R[4];
+        const int g0 = NMOT + 3 * c;
+        const real vn = rdlane(v, g0);
+        real vt1 = rdlane(v, g0 + 1), vt2 = rdlane(v, g0 + 2);
+        const real l0 = q4.x, l1 = q4.y, l2 = q4.z;
+        real s0 = l0 + (q0.x - vn * q2.y);
+        s0 = max_(s0, q1.w);
+        const real dl0 = s0 - l0;
+        busy |= __ballot(absr(dl0) > q3.x);
+        real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
+        if (rdlane(s0, 0) > 0 || rdlane(q1.z, 0) < 0) {   // wave-uniform (Bullet skips the friction rows of an unloaded contact)
+          const real hi = max_(q1.z * s0, q2.x);
+          vt1 += q0.w * dl0;
+          s1 = l1 + (q0.y - vt1 * q2.z); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
+          busy |= __ballot(absr(dl1) > q3.y);
+          vt2 += q1.x * dl0 + q1.y * dl1;
+          s2 = l2 + (q0.z - vt2 * q2.w); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
+          busy |= __ballot(absr(dl2) > q3.z);
+        }
+        if (lane == 0) { Rw[16] = s0; Rw[17] = s1; Rw[18] = s2; }
+        v += A[g0] * dl0 + A[g0 + 1] * dl1 + A[g0 + 2] * dl2;
+      }
+    }
+    return busy == 0;
+  };
+  int it = 0;
+  while (it < P.iters) {
+    it++; if (iterate()) break;
+    if (it >= P.iters) break;
+    it++; if (iterate()) break;
+  }
+  w.sync();
+  // ---- multipliers of the contacts back to r_lam; DOF velocities du = sum over rows of W_row * lambda_row (lane = DOF)
+  if (lane < nc) { const real* R = sh.b.crec[lane]; sh.r_lam[3 * lane] = R[16]; sh.r_lam[3 * lane + 1] = R[17]; sh.r_lam[3 * lane + 2] = R[18]; }
+  w.sync();
+  {
+    const int d = lane, dw = d < ND ? d : ND;
+    real du = 0;
+    if (d < 9) {
+#pragma unroll
+      for (int j = 0; j < 9; j++) du += wma_row(sh, j)[d] * (lam_a[j] + lam_lo[j] - lam_hi[j]);
+    } else if (d < ND) {
+#pragma unroll
+      for (int j = 0; j < PIH_OBJ_NJ; j++) du += wmp_row(sh, j)[d - 9] * lam_p[j];
+    }
+#pragma unroll
+    for (int c = 0; c < MERGED_CONTACTS; c++)
+      if (c < nc) du += sh.b.Wp[3 * c][dw] * sh.r_lam[3 * c] + sh.b.Wp[3 * c + 1][dw] * sh.r_lam[3 * c + 1] + sh.b.Wp[3 * c + 2][dw] * sh.r_lam[3 * c + 2];
+    if (d < ND) sh.u[d] += du;
+  }
+  w.sync();
+  return it;
+}
+
 // Sequential impulse, Bullet resolveSingleConstraintRowGeneric form; row order: per arm joint (motor, lower limit, upper
 // limit), the 23 pipe motors, then per contact (normal, dir1, dir2).  Returns iterations executed.
 // GPU form: one lane per DOF holds its entry of the velocity change `du`; row multipliers live lane-distributed in
@@ -264,6 +457,7 @@ PIH_HD void row16_sum3(real& a, real& b, real& c) {
 // DPP row-reductions in flight at once, then the cross terms G bring dir1/dir2 up to date without touching `du`.
 PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW& mw) {
   const int nc = sh.nc;
+  if (P.pgsmode == 0 && nc <= MERGED_CONTACTS) return pgs_rows(w, sh, P);   // all rows fit one wavefront: row-space solver
   // early exit test without divisions: (dl / dinv)^2 <= resid  <=>  dl^2 - resid dinv^2 <= 0  for every row
   w.sync();
   const int d = w.lane();

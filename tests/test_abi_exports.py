@@ -21,9 +21,9 @@ def test_every_declared_symbol_is_exported():
 
 def test_config_struct_layout_matches_header():
     from peg_in_hole_gym_amd import _lib
-    assert ctypes.sizeof(_lib.PihConfig) == 12 * 4 + 8 + 12 * 4     # 12 int32 (task_id last), u64 seed, 12 floats
-    assert _lib.PihConfig.task_id.offset == 44
-    assert _lib.PihConfig.seed.offset == 48 and _lib.PihConfig.dt.offset == 56
+    assert ctypes.sizeof(_lib.PihConfig) == 14 * 4 + 8 + 12 * 4     # 14 int32 (task_id, solver_path, reserved), u64 seed, 12 floats
+    assert _lib.PihConfig.task_id.offset == 44 and _lib.PihConfig.solver_path.offset == 48
+    assert _lib.PihConfig.seed.offset == 56 and _lib.PihConfig.dt.offset == 64
     c = _lib.default_config()
     assert c.solver_iters == 50 and c.ik_iters == 20 and abs(c.dt - 1 / 240) < 1e-9 and c.max_episode_steps == 2227 and c.enable_arm_collision == 1 and c.task_id == 0
 
