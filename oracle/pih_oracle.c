@@ -469,7 +469,7 @@ struct piho_handle { piho_config cfg; Env* env; void* rows_ws[MAXTHREADS]; };
 void piho_default_config(piho_config* c) {
   memset(c, 0, sizeof *c);
   c->n_envs = 1; c->mode = 0; c->solver_iters = 50; c->ik_iters = 20; c->max_episode_steps = 2227; c->auto_reset = 0;
-  c->enable_self_collision = 1; c->enable_arm_collision = 1; c->seed = 0; c->dt = 1.0 / 240.0; c->residual_threshold = 1e-7; c->erp = 0.2;
+  c->enable_self_collision = 1; c->enable_arm_collision = 3; c->seed = 0; c->dt = 1.0 / 240.0; c->residual_threshold = 1e-7; c->erp = 0.2;
   c->warmstart = 0.85; c->contact_margin = 0.005; c->linear_slop = 1e-5; c->ik_damping = 0.5; c->ik_residual = 1e-4;
   c->dv = 2.0 / 240.0;
 }
@@ -641,7 +641,7 @@ static void collide(const piho_config* c, Env* E, const LinkKin* K) {
   }
   /* arm collision spheres vs the table plane (linkA = arm link, linkB = world; keys 3000+): they count against the
    * arm-contact cap and come before the finger contacts, so a finger-vs-pipe contact is what gets dropped first */
-  if (c->enable_arm_collision)
+  if (c->enable_arm_collision & 1)
     for (int i = 0; i < PIH_ARM_NSPH; i++) {
       const LinkKin* k = &K[ASPH_LINK[i]];
       v3 cw; m_mulv(cw, k->R, ASPH_C[i]); v_add(cw, cw, k->o);
@@ -677,6 +677,23 @@ static void collide(const piho_config* c, Env* E, const LinkKin* K) {
       nca += add_contact(E, L, PIH_FINGER_LINK0 + f, 300 + f * PIH_PIPE_NSAMP + i, p, n, depth, L_MU[L] * L_MU[PIH_FINGER_LINK0 + f]);
     }
   }
+  /* arm collision spheres vs the pipe (enable_arm_collision bit 1; the reference loads the full panda.urdf collision model,
+   * envs/utils.py:31-34): every pipe sample sphere against the hand / flange / wrist spheres PIH_ARM_PIPE_SPH0.. (finger tips are
+   * covered by the pad boxes), deepest sphere per sample; keys 5000 + sphere * NSAMP + sample; last of the arm-involving contacts */
+  if (c->enable_arm_collision & 2)
+    for (int i = 0; i < PIH_PIPE_NSAMP; i++) {
+      real best = margin; int bs = -1; v3 bn = {0, 0, 0};
+      for (int s = PIH_ARM_PIPE_SPH0; s < PIH_ARM_NSPH; s++) {
+        const LinkKin* k = &K[ASPH_LINK[s]];
+        v3 cw, d; m_mulv(cw, k->R, ASPH_C[s]); v_add(cw, cw, k->o); v_sub(d, sp[i], cw);
+        real dist = v_norm(d), dep = dist - r - ASPH_R[s];
+        if (dep < best && dist > 1e-9) { best = dep; bs = s; v_set(bn, d[0] / dist, d[1] / dist, d[2] / dist); }
+      }
+      if (bs < 0 || nca >= PIHO_CAMAX) continue;
+      v3 p; v_cp(p, sp[i]); v_axpy(p, -(r + 0.5 * best), bn);
+      int L = ANL + SAMP_LINK[i];
+      nca += add_contact(E, L, ASPH_LINK[bs], 5000 + bs * PIH_PIPE_NSAMP + i, p, bn, best, L_MU[L] * L_MU[ASPH_LINK[bs]]);
+    }
   /* pipe self collision (URDF_USE_SELF_COLLISION, envs/peg_in_hole.py:242): capsule segments s<t, non adjacent */
   if (c->enable_self_collision) {
     v3 vtx[25]; int nv = 0;

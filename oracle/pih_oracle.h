@@ -47,7 +47,7 @@ typedef struct {
   int32_t auto_reset;         /* 1: envs that finish are reset inside step() */
   int32_t enable_self_collision;
   int32_t env_index0;         /* global index of env 0 (block partition across ranks): env seeds = seed + 1000 + global index */
-  int32_t enable_arm_collision; /* 1: arm collision spheres (pih_model.h PIH_ARM_SPH_*) vs the table plane */
+  int32_t enable_arm_collision; /* arm collision spheres (pih_model.h PIH_ARM_SPH_*): bit 0 vs the table plane, bit 1 vs the pipe; default 3 */
   uint64_t seed;
   piho_real dt;                  /* 1/240 */
   piho_real residual_threshold;  /* 1e-7 (squared velocity residual), 0 = never exit early */

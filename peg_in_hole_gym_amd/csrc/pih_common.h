@@ -113,6 +113,7 @@ struct ArenaA {
   alignas(16) real IAP[NL][28];   // per link: own spatial inertia about the link origin (A6 B9 C6) + bias force (6) + pad
   real CB[NL][6];                  // velocity-product accelerations, then (alpha, acc) of each link
   real SP[NSAMP][3];               // collision sample spheres
+  real ASP[PIH_ARM_NSPH][3];       // arm collision sphere centres (world)
 };
 struct ArenaB {
   // response rows of the first CL contacts; the 32 motor response rows (Wmp 23 x WMS, then Wma 9 x 9) are staged in the
@@ -506,16 +507,18 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
     });
     nca += w.alloc_count() - before;
   }
-  // arm collision spheres vs the table plane (linkA = arm link, linkB = world; keys 3000+): they count against the
+  // arm collision spheres (pih_model.h PIH_ARM_SPH_*, PROVISIONAL stand-ins for the Panda collision meshes of pybullet_data)
+  if (P.armcol) w.par(PIH_ARM_NSPH, [&](int i) { const int L = ASPH_LINK[i]; st3(sh.a.ASP[i], ld3(sh.LO[L]) + mul(ldm(sh.a.LR[L]), ld3(ASPH_C[i]))); });
+  // ... vs the table plane (enable_arm_collision bit 0; linkA = arm link, linkB = world; keys 3000+): they count against the
   // arm-contact cap and come before the finger contacts, so a finger-vs-pipe contact is what gets dropped first
-  if (P.armcol) {
+  if (P.armcol & 1) {
     const int before = w.alloc_count();
     const int allowed = CAMAX - nca;
     w.par_all(PIH_ARM_NSPH, [&](int i, bool in) {
       bool valid = false; V3 cw = mk(0, 0, 0); real depth = 0, rs = 0; int L = 0;
       if (in) {
         L = ASPH_LINK[i]; rs = ASPH_R[i];
-        cw = ld3(sh.LO[L]) + mul(ldm(sh.a.LR[L]), ld3(ASPH_C[i]));
+        cw = ld3(sh.a.ASP[i]);
         depth = cw.z - (real)PIH_TABLE_Z - rs;
         valid = depth < margin;
       }
@@ -558,6 +561,32 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
     });
     int used = w.alloc_count() - before;
     if (used > allowed) { used = allowed; w.alloc_reset(before + allowed); }   // the dropped ones are the tail of this pass
+    nca += used;
+  }
+  // ... vs the pipe (enable_arm_collision bit 1; the reference loads the full panda.urdf collision model, envs/utils.py:31-34, so
+  // hand and wrist cannot pass through the pipe): every pipe sample sphere against the hand / flange / wrist spheres
+  // PIH_ARM_PIPE_SPH0.. (the finger tips are covered by the pad boxes above), deepest sphere per sample; keys 5000 + sphere * NSAMP +
+  // sample.  Last of the arm-involving contacts, so they are the first to be dropped at the cap.
+  if (P.armcol & 2) {
+    const int before = w.alloc_count();
+    const int allowed = CAMAX - nca;
+    w.par_all(NSAMP, [&](int i, bool in) {
+      bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = margin; int L = 0, bs = 0;
+      if (in) {
+        const V3 sp = ld3(sh.a.SP[i]);
+#pragma unroll
+        for (int s = PIH_ARM_PIPE_SPH0; s < PIH_ARM_NSPH; s++) {
+          const V3 d = sp - ld3(sh.a.ASP[s]);
+          const real dist = norm(d), dep = dist - r - ASPH_R[s];
+          if (dep < depth && dist > (real)1e-9) { depth = dep; bs = s; n = ((real)1 / dist) * d; valid = true; }
+        }
+        if (valid) { p = sp - (r + (real)0.5 * depth) * n; L = ANL + SAMP_LINK[i]; }
+      }
+      int slot = w.alloc(valid);
+      if (valid && slot < CMAX && (slot - before) < allowed) emit(slot, L, ASPH_LINK[bs], 5000 + bs * NSAMP + i, p, n, depth, L_MU[L] * L_MU[ASPH_LINK[bs]]);
+    });
+    int used = w.alloc_count() - before;
+    if (used > allowed) { used = allowed; w.alloc_reset(before + allowed); }
     nca += used;
   }
   // pipe self collision: capsule segments s < t, non adjacent (253 pairs, enumerated in key order)

@@ -339,7 +339,7 @@ extern "C" {
 void pih_default_config(pih_config* c) {
   memset(c, 0, sizeof *c);
   c->n_envs = 1; c->env_index0 = 0; c->mode = 0; c->solver_iters = 50; c->ik_iters = 20; c->max_episode_steps = 2227;
-  c->auto_reset = 0; c->enable_self_collision = 1; c->enable_arm_collision = 1; c->task_id = PIH_TASK_PEG_IN_HOLE; c->debug = 0; c->schedule = 1; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
+  c->auto_reset = 0; c->enable_self_collision = 1; c->enable_arm_collision = 3; c->task_id = PIH_TASK_PEG_IN_HOLE; c->debug = 0; c->schedule = 1; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
   c->erp = 0.2f; c->warmstart = 0.85f; c->contact_margin = 0.005f; c->linear_slop = 1e-5f; c->ik_damping = 0.5f; c->ik_residual = 1e-4f;
   c->dv = 2.0f / 240.0f;
 }

@@ -21,7 +21,7 @@ class PihConfig(C.Structure):
 
 def default_config(**kw):
     c = PihConfig(n_envs=1, env_index0=0, mode=0, solver_iters=50, ik_iters=20, max_episode_steps=2227, auto_reset=0,
-                  enable_self_collision=1, enable_arm_collision=1, debug=0, seed=0, dt=1.0 / 240.0, residual_threshold=1e-7, erp=0.2, warmstart=0.85,
+                  enable_self_collision=1, enable_arm_collision=3, debug=0, seed=0, dt=1.0 / 240.0, residual_threshold=1e-7, erp=0.2, warmstart=0.85,
                   contact_margin=0.005, linear_slop=1e-5, ik_damping=0.5, ik_residual=1e-4, dv=2.0 / 240.0)
     for k, v in kw.items():
         if not hasattr(c, k):

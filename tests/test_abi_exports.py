@@ -25,7 +25,7 @@ def test_config_struct_layout_matches_header():
     assert _lib.PihConfig.task_id.offset == 44 and _lib.PihConfig.solver_path.offset == 48
     assert _lib.PihConfig.seed.offset == 56 and _lib.PihConfig.dt.offset == 64
     c = _lib.default_config()
-    assert c.solver_iters == 50 and c.ik_iters == 20 and abs(c.dt - 1 / 240) < 1e-9 and c.max_episode_steps == 2227 and c.enable_arm_collision == 1 and c.task_id == 0
+    assert c.solver_iters == 50 and c.ik_iters == 20 and abs(c.dt - 1 / 240) < 1e-9 and c.max_episode_steps == 2227 and c.enable_arm_collision == 3 and c.task_id == 0
 
 
 def test_create_fails_loudly_without_gpu():

@@ -1,0 +1,24 @@
+"""Diagnostic: per-env shader-clock cycles of pih_step_kernel (config.debug = 2 stamps) by contact count, for both PGS paths.
+usage: python tools/env_cycles.py [n_envs]      Not a benchmark (the stamps cost ~10 %)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from peg_in_hole_gym_amd.vec_env import PihVecEnv
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+for path in (0, 1):
+    env = PihVecEnv(n, auto_reset=1, debug=2, solver_path=path, max_episode_steps=2227)
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    tot = []; pgs = []; cnt = []
+    for t in range(460):
+        env.step(torch.rand(n, 4, device="cuda", generator=gen) * 2 - 1)
+        if t >= 400 and t % 5 == 0:
+            d = env.debug()
+            tot.append(d[:, 900:908].sum(1)); pgs.append(d[:, 905]); cnt.append(env.state()[:, 106])
+    tot = torch.cat(tot); pgs = torch.cat(pgs); cnt = torch.cat(cnt)
+    q = lambda x, p: float(torch.quantile(x.float(), p))
+    print("solver_path %d: per-env cycles mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f | PGS mean %.0f | mean contacts %.2f | sum/2048 slots %.0f" % (
+        path, tot.mean(), q(tot, .5), q(tot, .9), q(tot, .99), tot.max(), pgs.mean(), cnt.mean(), tot.sum() / len(tot) * n / 2048))
+    for lo, hi in ((0, 4), (5, 7), (8, 10), (11, 14), (15, 19), (20, 48)):
+        m = (cnt >= lo) & (cnt <= hi)
+        if m.any():
+            print("   contacts %2d..%2d: %5.1f %% of env-steps, total %.0f cycles, PGS %.0f" % (lo, hi, 100 * m.float().mean(), tot[m].mean(), pgs[m].mean()))

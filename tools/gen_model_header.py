@@ -223,6 +223,7 @@ print("#define PIH_ARM_NSPH %d" % len(ARM_SPH))
 print("#define PIH_ARM_SPH_LINK " + iarr(a[0] for a in ARM_SPH))
 print("#define PIH_ARM_SPH_C {" + ", ".join(arr(a[1]) for a in ARM_SPH) + "}")
 print("#define PIH_ARM_SPH_R " + arr(a[2] for a in ARM_SPH))
+print("#define PIH_ARM_PIPE_SPH0 2   /* spheres 2.. (hand x3, flange, link 6/5/4 origins) also collide with the pipe; 0, 1 = finger tips (pad boxes do that) */")
 print("/* pipe collision rope */")
 print("#define PIH_PIPE_RADIUS %s" % fmt(PIPE_R))
 print("#define PIH_PIPE_NSAMP %d" % len(samples))
