@@ -4,6 +4,7 @@
 // row_bcast, 16-byte LDS broadcasts -- forward kinematics as a prefix product of rigid transforms, link velocities as prefix
 // sums, the entry-parallel inward sweep of the articulated-body algorithm, and the sequential-impulse PGS.
 #pragma once
+#include <type_traits>
 #include "pih_common.h"
 
 namespace pih {
@@ -334,98 +335,139 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
     const real d0 = R[11], d1 = R[15], d2 = R[19], t0 = R[29], t1 = R[30], t2 = R[31];
     R[0] = r0; R[1] = r1; R[2] = r2; R[3] = g10; R[4] = g20; R[5] = g21; R[6] = mu; R[7] = lon;
     R[8] = hif; R[9] = d0; R[10] = d1; R[11] = d2; R[12] = t0; R[13] = t1; R[14] = t2; R[15] = 0;
-    R[16] = sh.r_lam[3 * lane]; R[17] = 0; R[18] = 0; R[19] = 0;      // warm start
   }
   w.sync();
+  // ---- the limit rows of arm joints 0..6 are exact no-ops for the whole solve when (a) the joint's motor row is never clamped --
+  // an unclamped velocity motor sets the joint's velocity change to (target - current) whatever it was, because J W dinv = 1 -- and
+  // (b) that target velocity violates neither limit speed: then  rhs_limit - (J du) dinv = (v_limit - v_target) dinv < 0  every time
+  // and the multiplier stays 0.  (b) is known before the solve (skip7, wave-uniform); (a) is watched during the solve (one compare
+  // per arm motor row) and, should a motor ever clamp, the solve is simply run again with every limit row in place.  The finger
+  // joints (targets far outside [0, 0.04] most of the time) always keep their limit rows.
+  bool skip7 = true;
+  {
+    const real dt = P.dt;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      const real q = sh.S[PIH_S_QARM + j], uj = sh.u[j];
+      const real vt = sh.mrec[j][1] * sh.lrec[j][2] + uj;                         // rhs / dinv + u = the motor's target velocity
+      const real plo = q - L_LO[j], phi = L_HI[j] - q;
+      const real vlo = plo > 0 ? -plo / dt : -P.erp * plo / dt, vhi = phi > 0 ? -phi / dt : -P.erp * phi / dt;
+      const real tol = (real)1e-4 * ((real)1 + absr(vt) + absr(uj) + absr(vlo) + absr(vhi));
+      skip7 = skip7 && (vt - vlo > tol) && (-vhi - vt > tol);
+    }
+    skip7 = __builtin_amdgcn_readfirstlane((int)skip7) != 0;
+  }
   // ---- multipliers: wave-uniform values in VGPRs
   real lam_p[PIH_OBJ_NJ], lam_a[9], lam_lo[9], lam_hi[9];
-#pragma unroll
-  for (int j = 0; j < PIH_OBJ_NJ; j++) lam_p[j] = 0;
-#pragma unroll
-  for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
   real v = 0;
-#pragma unroll
-  for (int c = 0; c < MERGED_CONTACTS; c++)
-    if (c < nc) v += A[NMOT + 3 * c] * sh.r_lam[3 * c];   // warm start
-  auto iterate = [&]() __attribute__((always_inline)) -> bool {
-    unsigned long long busy = 0;
-    __asm__ volatile("" ::: "memory");      // keep the row constants in LDS (see pgs(): LICM would hoist and spill them)
-    constexpr int PF = 4;
-    real4 pm[PF], pa4[PF], pl4[PF];
-#pragma unroll
-    for (int k = 0; k < PF; k++) { pm[k] = *reinterpret_cast<const real4*>(sh.mrec[9 + k]); pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
-    // the arm rows and the pipe motor rows do not see each other (A[arm row][pipe motor row] = 0): two accumulators, two chains
-    real va = v, vp = v;
-#pragma unroll
-    for (int j = 0; j < PIH_OBJ_NJ; j++) {
-      const real4 cm = pm[j % PF];
-      if (j + PF < PIH_OBJ_NJ) pm[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[9 + j + PF]);
-      if (j < 9) {   // arm joint block: motor, lower limit, upper limit
-        const real4 ca = pa4[j % PF], cl = pl4[j % PF];
-        if (j + PF < 9) { pa4[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[j + PF]); pl4[j % PF] = *reinterpret_cast<const real4*>(sh.lrec[j + PF]); }
-        const real di = ca.x, rhs = ca.y, thr = ca.z, lim = ca.w;
-        const real lor = cl.x, hir = cl.y, wjj = cl.z;
-        real dj = rdlane(va, j);
-        real sum = lam_a[j] + (rhs - dj * di);
-        sum = med3_(sum, -lim, lim);
-        const real dl = sum - lam_a[j]; lam_a[j] = sum;
-        busy |= __ballot(absr(dl) > thr);
-        dj += dl * wjj;
-        real s2 = lam_lo[j] + (lor - dj * di); s2 = max_(s2, (real)0);
-        const real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
-        busy |= __ballot(absr(d2) > thr);
-        dj += d2 * wjj;
-        real s3 = lam_hi[j] + (hir + dj * di); s3 = max_(s3, (real)0);
-        const real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
-        busy |= __ballot(absr(d3) > thr);
-        va += A[j] * (dl + d2 - d3);
-      }
-      const real di = cm.x, rhs = cm.y, thr = cm.z, lim = cm.w;
-      const real dj = rdlane(vp, 9 + j);
-      real sum = lam_p[j] + (rhs - dj * di);
-      sum = med3_(sum, -lim, lim);
-      const real dl = sum - lam_p[j]; lam_p[j] = sum;
-      busy |= __ballot(absr(dl) > thr);
-      vp += A[9 + j] * dl;
-    }
-    v = (va + vp) - v;
-    // contacts: exact 3x3 Gauss-Seidel block in row space
-#pragma unroll
-    for (int c = 0; c < MERGED_CONTACTS; c++) {
-      if (c < nc) {
-        real* Rw = sh.b.crec[c];
-        const real4* R = reinterpret_cast<const real4*>(Rw);
-        const real4 q0 = R[0], q1 = R[1], q2 = R[2], q3 = R[3], q4 = R[4];
-        const int g0 = NMOT + 3 * c;
-        const real vn = rdlane(v, g0);
-        real vt1 = rdlane(v, g0 + 1), vt2 = rdlane(v, g0 + 2);
-        const real l0 = q4.x, l1 = q4.y, l2 = q4.z;
-        real s0 = l0 + (q0.x - vn * q2.y);
-        s0 = max_(s0, q1.w);
-        const real dl0 = s0 - l0;
-        busy |= __ballot(absr(dl0) > q3.x);
-        real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
-        if (rdlane(s0, 0) > 0 || rdlane(q1.z, 0) < 0) {   // wave-uniform (Bullet skips the friction rows of an unloaded contact)
-          const real hi = max_(q1.z * s0, q2.x);
-          vt1 += q0.w * dl0;
-          s1 = l1 + (q0.y - vt1 * q2.z); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
-          busy |= __ballot(absr(dl1) > q3.y);
-          vt2 += q1.x * dl0 + q1.y * dl1;
-          s2 = l2 + (q0.z - vt2 * q2.w); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
-          busy |= __ballot(absr(dl2) > q3.z);
-        }
-        if (lane == 0) { Rw[16] = s0; Rw[17] = s1; Rw[18] = s2; }
-        v += A[g0] * dl0 + A[g0 + 1] * dl1 + A[g0 + 2] * dl2;
-      }
-    }
-    return busy == 0;
-  };
   int it = 0;
-  while (it < P.iters) {
-    it++; if (iterate()) break;
-    if (it >= P.iters) break;
-    it++; if (iterate()) break;
-  }
+  auto solve = [&](auto FULLTAG) __attribute__((always_inline)) -> bool {     // returns true if an arm motor row clamped
+    constexpr bool FULL = decltype(FULLTAG)::value;
+#pragma unroll
+    for (int j = 0; j < PIH_OBJ_NJ; j++) lam_p[j] = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
+    v = 0;
+#pragma unroll
+    for (int c = 0; c < MERGED_CONTACTS; c++)
+      if (c < nc) { v += A[NMOT + 3 * c] * sh.r_lam[3 * c]; if (lane == 0) { real* R = sh.b.crec[c]; R[16] = sh.r_lam[3 * c]; R[17] = 0; R[18] = 0; } }   // warm start
+    unsigned long long clamped = 0;
+    auto iterate = [&]() __attribute__((always_inline)) -> bool {
+      unsigned long long busy = 0;
+      __asm__ volatile("" ::: "memory");      // keep the row constants in LDS (see pgs(): LICM would hoist and spill them)
+      constexpr int PF = 4;
+      real4 pm[PF], pa4[PF], pl4[PF];
+#pragma unroll
+      for (int k = 0; k < PF; k++) { pm[k] = *reinterpret_cast<const real4*>(sh.mrec[9 + k]); pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
+      // the first contact's constants are fetched before the motor chain, each further one while its predecessor is being solved
+      struct CQ { real4 q0, q1, q2, q3, q4; };
+      auto fetchc = [&](int c) __attribute__((always_inline)) -> CQ {
+        const real4* R = reinterpret_cast<const real4*>(sh.b.crec[c]);
+        CQ r; r.q0 = R[0]; r.q1 = R[1]; r.q2 = R[2]; r.q3 = R[3]; r.q4 = R[4]; return r;
+      };
+      CQ cq = fetchc(0);
+      // the arm rows and the pipe motor rows do not see each other (A[arm row][pipe motor row] = 0): two accumulators, two chains
+      real va = v, vp = v;
+#pragma unroll
+      for (int j = 0; j < PIH_OBJ_NJ; j++) {
+        const real4 cm = pm[j % PF];
+        if (j + PF < PIH_OBJ_NJ) pm[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[9 + j + PF]);
+        if (j < 9) {   // arm joint block: motor, lower limit, upper limit
+          const real4 ca = pa4[j % PF], cl = pl4[j % PF];
+          if (j + PF < 9) { pa4[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[j + PF]); pl4[j % PF] = *reinterpret_cast<const real4*>(sh.lrec[j + PF]); }
+          const real di = ca.x, rhs = ca.y, thr = ca.z, lim = ca.w;
+          const real lor = cl.x, hir = cl.y, wjj = cl.z;
+          real dj = rdlane(va, j);
+          real sum = lam_a[j] + (rhs - dj * di);
+          sum = med3_(sum, -lim, lim);
+          const real dl = sum - lam_a[j]; lam_a[j] = sum;
+          busy |= __ballot(absr(dl) > thr);
+          if (FULL || j >= 7) {
+            dj += dl * wjj;
+            real s2 = lam_lo[j] + (lor - dj * di); s2 = max_(s2, (real)0);
+            const real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
+            busy |= __ballot(absr(d2) > thr);
+            dj += d2 * wjj;
+            real s3 = lam_hi[j] + (hir + dj * di); s3 = max_(s3, (real)0);
+            const real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
+            busy |= __ballot(absr(d3) > thr);
+            va += A[j] * (dl + d2 - d3);
+          } else {
+            clamped |= __ballot(absr(sum) >= lim);
+            va += A[j] * dl;
+          }
+        }
+        const real di = cm.x, rhs = cm.y, thr = cm.z, lim = cm.w;
+        const real dj = rdlane(vp, 9 + j);
+        real sum = lam_p[j] + (rhs - dj * di);
+        sum = med3_(sum, -lim, lim);
+        const real dl = sum - lam_p[j]; lam_p[j] = sum;
+        busy |= __ballot(absr(dl) > thr);
+        vp += A[9 + j] * dl;
+      }
+      v = (va + vp) - v;
+      // contacts: exact 3x3 Gauss-Seidel block in row space
+      //   q0 = rhs n,t1,t2, G[t1][n] | q1 = G[t2][n], G[t2][t1], mu, lo_n | q2 = hi_floor, dinv n,t1,t2 | q3 = thr n,t1,t2 | q4 = lambda n,t1,t2
+#pragma unroll
+      for (int c = 0; c < MERGED_CONTACTS; c++) {
+        if (c < nc) {
+          const CQ r = cq;
+          if (c + 1 < MERGED_CONTACTS) cq = fetchc(c + 1 < nc ? c + 1 : c);
+          const real4 q0 = r.q0, q1 = r.q1, q2 = r.q2, q3 = r.q3, q4 = r.q4;
+          real* Rw = sh.b.crec[c];
+          const int g0 = NMOT + 3 * c;
+          const real vn = rdlane(v, g0);
+          real vt1 = rdlane(v, g0 + 1), vt2 = rdlane(v, g0 + 2);
+          const real l0 = q4.x, l1 = q4.y, l2 = q4.z;
+          real s0 = l0 + (q0.x - vn * q2.y);
+          s0 = max_(s0, q1.w);
+          const real dl0 = s0 - l0;
+          busy |= __ballot(absr(dl0) > q3.x);
+          real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
+          if (rdlane(s0, 0) > 0 || rdlane(q1.z, 0) < 0) {   // wave-uniform (Bullet skips the friction rows of an unloaded contact)
+            const real hi = max_(q1.z * s0, q2.x);
+            vt1 += q0.w * dl0;
+            s1 = l1 + (q0.y - vt1 * q2.z); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
+            busy |= __ballot(absr(dl1) > q3.y);
+            vt2 += q1.x * dl0 + q1.y * dl1;
+            s2 = l2 + (q0.z - vt2 * q2.w); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
+            busy |= __ballot(absr(dl2) > q3.z);
+          }
+          if (lane == 0) { Rw[16] = s0; Rw[17] = s1; Rw[18] = s2; }
+          v += A[g0] * dl0 + A[g0 + 1] * dl1 + A[g0 + 2] * dl2;
+        }
+      }
+      return busy == 0;
+    };
+    it = 0;
+    while (it < P.iters) {
+      it++; if (iterate()) break;
+      if (it >= P.iters) break;
+      it++; if (iterate()) break;
+    }
+    return clamped != 0;
+  };
+  if (!skip7 || solve(std::false_type{})) solve(std::true_type{});
   w.sync();
   // ---- multipliers of the contacts back to r_lam; DOF velocities du = sum over rows of W_row * lambda_row (lane = DOF)
   if (lane < nc) { const real* R = sh.b.crec[lane]; sh.r_lam[3 * lane] = R[16]; sh.r_lam[3 * lane + 1] = R[17]; sh.r_lam[3 * lane + 2] = R[18]; }
