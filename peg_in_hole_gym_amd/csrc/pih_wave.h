@@ -430,32 +430,30 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       //   q0 = rhs n,t1,t2, G[t1][n] | q1 = G[t2][n], G[t2][t1], mu, lo_n | q2 = hi_floor, dinv n,t1,t2 | q3 = thr n,t1,t2 | q4 = lambda n,t1,t2
 #pragma unroll
       for (int c = 0; c < MERGED_CONTACTS; c++) {
-        if (c < nc) {
-          const CQ r = cq;
-          if (c + 1 < MERGED_CONTACTS) cq = fetchc(c + 1 < nc ? c + 1 : c);
-          const real4 q0 = r.q0, q1 = r.q1, q2 = r.q2, q3 = r.q3, q4 = r.q4;
-          real* Rw = sh.b.crec[c];
-          const int g0 = NMOT + 3 * c;
-          const real vn = rdlane(v, g0);
-          real vt1 = rdlane(v, g0 + 1), vt2 = rdlane(v, g0 + 2);
-          const real l0 = q4.x, l1 = q4.y, l2 = q4.z;
-          real s0 = l0 + (q0.x - vn * q2.y);
-          s0 = max_(s0, q1.w);
-          const real dl0 = s0 - l0;
-          busy |= __ballot(absr(dl0) > q3.x);
-          real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
-          if (rdlane(s0, 0) > 0 || rdlane(q1.z, 0) < 0) {   // wave-uniform (Bullet skips the friction rows of an unloaded contact)
-            const real hi = max_(q1.z * s0, q2.x);
-            vt1 += q0.w * dl0;
-            s1 = l1 + (q0.y - vt1 * q2.z); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
-            busy |= __ballot(absr(dl1) > q3.y);
-            vt2 += q1.x * dl0 + q1.y * dl1;
-            s2 = l2 + (q0.z - vt2 * q2.w); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
-            busy |= __ballot(absr(dl2) > q3.z);
-          }
-          if (lane == 0) { Rw[16] = s0; Rw[17] = s1; Rw[18] = s2; }
-          v += A[g0] * dl0 + A[g0 + 1] * dl1 + A[g0 + 2] * dl2;
+        if (c >= nc) break;                              // single exit: no per-contact merge of the 20-register prefetch buffer
+        const real4 q0 = cq.q0, q1 = cq.q1, q2 = cq.q2, q3 = cq.q3, q4 = cq.q4;
+        cq = fetchc(c + 1 < MERGED_CONTACTS ? c + 1 : c);   // unconditional: beyond the last contact the record is loaded and never used
+        real* Rw = sh.b.crec[c];
+        const int g0 = NMOT + 3 * c;
+        const real vn = rdlane(v, g0);
+        real vt1 = rdlane(v, g0 + 1), vt2 = rdlane(v, g0 + 2);
+        const real l0 = q4.x, l1 = q4.y, l2 = q4.z;
+        real s0 = l0 + (q0.x - vn * q2.y);
+        s0 = max_(s0, q1.w);
+        const real dl0 = s0 - l0;
+        busy |= __ballot(absr(dl0) > q3.x);
+        real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
+        if (rdlane(s0, 0) > 0 || rdlane(q1.z, 0) < 0) {   // wave-uniform (Bullet skips the friction rows of an unloaded contact)
+          const real hi = max_(q1.z * s0, q2.x);
+          vt1 += q0.w * dl0;
+          s1 = l1 + (q0.y - vt1 * q2.z); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
+          busy |= __ballot(absr(dl1) > q3.y);
+          vt2 += q1.x * dl0 + q1.y * dl1;
+          s2 = l2 + (q0.z - vt2 * q2.w); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
+          busy |= __ballot(absr(dl2) > q3.z);
         }
+        if (lane == 0) { Rw[16] = s0; Rw[17] = s1; Rw[18] = s2; }
+        v += A[g0] * dl0 + A[g0 + 1] * dl1 + A[g0 + 2] * dl2;
       }
       return busy == 0;
     };
