@@ -18,12 +18,16 @@ def coil_pipe_flat(s):
 
 
 def stiff_finger_contact(contacts):
-    """True if the oracle's contact list ([k,12]: linkA linkB p n depth mu key lambda_n) holds a LOADED arm contact (finger pad or
-    hand / wrist sphere) with the clamped friction mu = 10 (on one of the pipe's 11-gram end links, URDF friction 100): with pyramid
-    friction that large PGS is not a contraction, so rounding differences between two implementations are amplified within one
-    step (the fp64 build of the product algorithm shows the same against the fp64 oracle)."""
+    """True if the oracle's contact list ([k,12]: linkA linkB p n depth mu key lambda_n) describes an ILL-CONDITIONED step for PGS:
+    the arm (finger pad, hand or wrist sphere) presses on the pipe while a contact with the clamped friction mu = 10 is loaded
+    (one of the pipe's 11-gram end links, URDF friction 100, against a finger, the hand or the table).  With pyramid friction that
+    large on a body that light, 50 PGS iterations are not a contraction, so rounding differences between two implementations are
+    amplified within one step (the fp64 build of the product algorithm shows the same against the fp64 oracle, and
+    so do the two fp32 solver paths of the product against each other)."""
     c = np.asarray(contacts)
     if len(c) == 0:
         return False
-    finger = (c[:, 1] >= 0) & (c[:, 1] <= 8)
-    return bool((finger & (c[:, 9] >= 10.0) & (c[:, 11] > 0)).any())
+    loaded = c[:, 11] > 0
+    arm = (c[:, 1] >= 0) & (c[:, 1] <= 8) & loaded
+    mu10 = (c[:, 9] >= 10.0) & loaded
+    return bool(arm.any() and mu10.any())
