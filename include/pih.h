@@ -48,6 +48,8 @@ enum {
   PIH_S_PGS_ITERS = 107,   /* PGS iterations actually executed in the last step */
   PIH_S_EE = 108,          /* world position of the grasp-target frame (pybullet link 11) after the last step / reset (3) */
   PIH_S_GRASP_ANGLE = 111, /* scripted mode: atan2 of the rotated grasp offset when the state machine entered state 2 (envs/peg_in_hole.py:72) */
+  PIH_S_ATTACH_QZ = 113,   /* scripted mode: z component of the grasped link's quaternion when the state machine entered state 4 (the
+                              reference passes it as targetOrn[2] into childFrameOrientation, envs/peg_in_hole.py:101) */
   PIH_S_INVALID = 112,     /* 1: the state became non-finite while auto_reset = 0; the env was re-initialised, marked done and stays frozen until pih_reset */
   PIH_S_CACHE_N = 128, PIH_S_CACHE_KEY = 129, PIH_S_CACHE_LAMBDA = 129 + 48
 };
@@ -98,7 +100,8 @@ typedef struct pih_config {
   int32_t task_id;            /* PIH_TASK_*: which task of TASK_LIST (envs/base_env.py:9-11) the handle simulates */
   int32_t solver_path;        /* 0 (default): envs with <= 10 contacts use the row-space PGS (all rows in one wavefront), the others the DOF-space
                                  PGS; 1: DOF-space PGS for every env (A/B runs and tests; same row sequence, results equal to rounding) */
-  int32_t reserved_i;
+  int32_t attach_ball;        /* p7 attach (createConstraint, envs/peg_in_hole.py:99-104): 0 (default) = 6-row weld honouring childFrameOrientation,
+                                 1 = 3-row ball joint between the grasp point and the grasp-target origin (round-1 behaviour) */
   uint64_t seed;
   float dt;                   /* 1/240 */
   float residual_threshold;   /* 1e-7 */

@@ -18,7 +18,7 @@ def _config_type(real):
     class _Config(C.Structure):
         _fields_ = [("n_envs", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32), ("ik_iters", C.c_int32),
                     ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("enable_self_collision", C.c_int32),
-                    ("env_index0", C.c_int32), ("enable_arm_collision", C.c_int32), ("seed", C.c_uint64), ("dt", real), ("residual_threshold", real),
+                    ("env_index0", C.c_int32), ("attach_ball", C.c_int32), ("enable_arm_collision", C.c_int32), ("seed", C.c_uint64), ("dt", real), ("residual_threshold", real),
                     ("erp", real), ("warmstart", real), ("contact_margin", real), ("linear_slop", real),
                     ("ik_damping", real), ("ik_residual", real), ("dv", real)]
     return _Config

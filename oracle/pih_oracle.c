@@ -332,6 +332,16 @@ static void jac_row(const LinkKin* K, int L, const v3 p, const v3 dir, real sign
   }
 }
 
+/* angular Jacobian row: d . omega(link L) as a function of the generalized velocity */
+static void jac_row_ang(const LinkKin* K, int L, const v3 dir, real sign, real* J) {
+  while (L >= 0) {
+    int d = link_dof(L);
+    if (L_JTYPE[L] == PIH_JT_FLOATING) { for (int k = 0; k < 3; k++) J[d + 3 + k] += sign * dir[k]; }
+    else if (L_JTYPE[L] == PIH_JT_REVOLUTE) J[d] += sign * v_dot(dir, K[L].a);
+    L = L_PARENT[L];
+  }
+}
+
 /* ------------------------------------------------------------------------------------------ IK (p2) */
 /* BussIK damped least squares as driven by pybullet's calculateInverseKinematics without null-space
  * arguments [UNVERIFIED restatement, SURVEY.md App. C]: per iteration
@@ -638,6 +648,23 @@ static void collide(const piho_config* c, Env* E, const LinkKin* K) {
     if (dist > 1e-9) v_set(n, d[0] / dist, d[1] / dist, d[2] / dist);
     v_add(p, a1, ee); v_set(p, 0.5 * p[0], 0.5 * p[1], 0.5 * p[2]);
     nca += add_contact(E, g == 0 ? ANL : NL - 1, PIH_EE_PARENT, 2000, p, n, dist, -1.0);
+    if (!c->attach_ball) {
+      /* ... and, as a WELD, three bilateral ANGULAR rows (mu = -2 marks them; `p` carries the rotation-vector error, n = x so that
+       * (n, t1, t2) is an orthonormal triad): the child frame R_link R_cf, R_cf = quat(euler(0, -pi, pi/2 + targetOrn[2])) as
+       * passed by the reference (childFrameOrientation, envs/peg_in_hole.py:101; targetOrn[2] is the z component of the link
+       * quaternion when state 4 is entered), must coincide with the parent frame (link 11, parentFrameOrientation = identity) */
+      real rpy[3] = {0.0, -PI, PI / 2 + E->s[PIHO_S_ATTACH_QZ]}, qcf[4], Rcf[9], Rc[9], Rerr[9], eRt[9], qe[4];
+      piho_quat_from_euler(rpy, qcf); q_to_m(Rcf, qcf);
+      m_mul(Rc, k->R, Rcf);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) eRt[3 * i + j] = eR[3 * j + i];
+      m_mul(Rerr, Rc, eRt);                       /* rotation of the child frame relative to the parent frame, world axes */
+      m_to_q(qe, Rerr);
+      real sn = sqrt(qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]), ang = 2 * atan2(sn, qe[3]);
+      if (ang > PI) ang -= 2 * PI;
+      v3 th = {0, 0, 0}, nx = {1, 0, 0};
+      if (sn > 1e-12) v_set(th, ang * qe[0] / sn, ang * qe[1] / sn, ang * qe[2] / sn);
+      nca += add_contact(E, g == 0 ? ANL : NL - 1, PIH_EE_PARENT, 2001, th, nx, 0.0, -2.0);
+    }
   }
   /* arm collision spheres vs the table plane (linkA = arm link, linkB = world; keys 3000+): they count against the
    * arm-contact cap and come before the finger contacts, so a finger-vs-pipe contact is what gets dropped first */
@@ -753,6 +780,7 @@ static void controller(const piho_config* c, Env* E, const real* action, const L
     v3 rv0 = {0, s[PIHO_S_RANDY], 0}, rv, tpos, tp;
     piho_rotate_vector(rv0, tip + 3, rv); v_add(tpos, tip, rv);
     if (st == 2 && st_prev != 2) s[PIHO_S_GRASP_ANGLE] = atan2(rv[1], rv[0]);   /* label angle, envs/peg_in_hole.py:72 */
+    if (st == 4 && st_prev != 4) s[PIHO_S_ATTACH_QZ] = tip[5];                   /* targetOrn[2] of envs/peg_in_hole.py:101: the z COMPONENT of the link quaternion */
     piho_vel_constraint(eep, tpos, c->dv, tp);                               /* grasp_process :125 */
     real eul[3]; piho_euler_from_quat(tip + 3, eul);
     real rpy[3], tq[4], qs[9]; int do_ik = 0;
@@ -845,8 +873,12 @@ static void step_env(piho_handle* h, int e, const real* action, real* obs, real*
       const real* dir = rep == 0 ? ct->n : (rep == 1 ? t1 : t2);
       Row* r = &rows[nr++];
       memset(r, 0, sizeof *r);
-      jac_row(K, ct->linkA, ct->p, dir, 1.0, r->J);
-      if (ct->linkB >= 0) jac_row(K, ct->linkB, ct->p, dir, -1.0, r->J);
+      const int ang = ct->mu < -1.5;                            /* angular rows of the attach weld */
+      if (ang) { jac_row_ang(K, ct->linkA, dir, 1.0, r->J); if (ct->linkB >= 0) jac_row_ang(K, ct->linkB, dir, -1.0, r->J); }
+      else {
+        jac_row(K, ct->linkA, ct->p, dir, 1.0, r->J);
+        if (ct->linkB >= 0) jac_row(K, ct->linkB, ct->p, dir, -1.0, r->J);
+      }
       memcpy(r->W, r->J, sizeof r->J); minv_apply(M, r->W);
       real jw = 0, ju = 0; for (int k = 0; k < ND; k++) { jw += r->J[k] * r->W[k]; ju += r->J[k] * u[k]; }
       r->dinv = 1.0 / jw;
@@ -854,9 +886,10 @@ static void step_env(piho_handle* h, int e, const real* action, real* obs, real*
         real pen = ct->depth + c->linear_slop;
         real vb = pen > 0 ? -pen / dt : -c->erp * pen / dt;
         if (ct->mu < 0) vb = -c->erp * ct->depth / dt;          /* attach: close the gap with ERP, both signs allowed */
+        if (ang) vb = -c->erp * v_dot(ct->p, dir) / dt;         /* weld: rotate the child frame back onto the parent frame */
         r->rhs = (vb - ju) * r->dinv; r->lo = ct->mu < 0 ? -1e30 : 0; r->hi = 1e30; r->fparent = -1;
         for (int k = 0; k < E->ncache; k++) if (E->cache_key[k] == ct->key) { r->lambda = c->warmstart * E->cache_lambda[k]; break; }
-      } else { r->rhs = -ju * r->dinv; r->fparent = row_n0 + 3 * i; r->mu = ct->mu; }
+      } else { r->rhs = ((ang ? -c->erp * v_dot(ct->p, dir) / dt : 0) - ju) * r->dinv; r->fparent = row_n0 + 3 * i; r->mu = ct->mu; }
     }
   }
 

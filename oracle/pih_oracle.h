@@ -35,7 +35,7 @@ enum {
   PIHO_S_QARM = 0, PIHO_S_QDARM = 9, PIHO_S_POS = 18, PIHO_S_QUAT = 21, PIHO_S_VLIN = 25, PIHO_S_VANG = 28,
   PIHO_S_QJ = 31, PIHO_S_QDJ = 54, PIHO_S_TARGET = 77,
   PIHO_S_FSM = 86, PIHO_S_FSMT = 87, PIHO_S_DONE = 88, PIHO_S_GRASP = 89, PIHO_S_RANDY = 90, PIHO_S_RNG_HI = 91,
-  PIHO_S_RNG = 92, PIHO_S_STEPS = 93, PIHO_S_OFFSET = 94, PIHO_S_SPARE = 97, PIHO_S_GRASP_ANGLE = 111, PIHO_S_INVALID = 112
+  PIHO_S_RNG = 92, PIHO_S_STEPS = 93, PIHO_S_OFFSET = 94, PIHO_S_SPARE = 97, PIHO_S_GRASP_ANGLE = 111, PIHO_S_INVALID = 112, PIHO_S_ATTACH_QZ = 113
 };
 
 typedef struct {
@@ -47,6 +47,7 @@ typedef struct {
   int32_t auto_reset;         /* 1: envs that finish are reset inside step() */
   int32_t enable_self_collision;
   int32_t env_index0;         /* global index of env 0 (block partition across ranks): env seeds = seed + 1000 + global index */
+  int32_t attach_ball;        /* 0 (default): p7 attach = 6-row weld honouring childFrameOrientation; 1: 3-row ball joint (round-1 behaviour) */
   int32_t enable_arm_collision; /* arm collision spheres (pih_model.h PIH_ARM_SPH_*): bit 0 vs the table plane, bit 1 vs the pipe; default 3 */
   uint64_t seed;
   piho_real dt;                  /* 1/240 */

@@ -92,7 +92,7 @@ typedef real areal;
 
 struct Params {
   real dt, resid, erp, warm, margin, slop, ikdamp, ikres, dv;
-  int iters, ikiters, mode, maxsteps, autoreset, selfcol, armcol, debug, env0, pgsmode;
+  int iters, ikiters, mode, maxsteps, autoreset, selfcol, armcol, debug, env0, pgsmode, attachball;
   uint64_t seed;
 };
 
@@ -391,6 +391,7 @@ PIH_HD void controller_targets(real* S, const Params& P, const real* action) {
     V3 tpos = mk(tip[0], tip[1], tip[2]) + rv;
     V3 tp = vel_constraint(eep, tpos, P.dv);
     if (st == 2 && st_prev != 2) S[PIH_S_GRASP_ANGLE] = (real)atan2(rv.y, rv.x);   // label angle, envs/peg_in_hole.py:72
+    if (st == 4 && st_prev != 4) S[PIH_S_ATTACH_QZ] = tip[5];                       // targetOrn[2] of envs/peg_in_hole.py:101 (z COMPONENT of the link quaternion)
     real yaw = yaw_from_quat(tornq);
     V3 hole = ld3(HOLE_POS);
     Q4 tq; tq.x = 0; tq.y = 0; tq.z = 0; tq.w = 1;
@@ -503,6 +504,28 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
         V3 d = a1 - ee; real dist = norm(d);
         V3 n = dist > (real)1e-9 ? ((real)1 / dist) * d : mk(1, 0, 0);
         emit(slot, L, PIH_EE_PARENT, 2000, (real)0.5 * (a1 + ee), n, dist, (real)-1);
+      }
+    });
+    // ... and, as a WELD (default; config.attach_ball = 1 keeps the ball joint alone), three bilateral ANGULAR rows (mu = -2 marks
+    // them; `p` carries the rotation-vector error, n = x so that (n, t1, t2) is an orthonormal triad): the child frame
+    // R_link R_cf, R_cf = quat(euler(0, -pi, pi/2 + targetOrn[2])) as the reference passes it (childFrameOrientation,
+    // envs/peg_in_hole.py:101), must coincide with the parent frame (link 11, parentFrameOrientation = identity)
+    w.par_all(1, [&](int i, bool in) {
+      bool valid = in && i == 0 && attached && !P.attachball;
+      int slot = w.alloc(valid);
+      if (valid && slot < CMAX) {
+        int g = (int)sh.S[PIH_S_GRASP];
+        int L = g == 0 ? ANL : NL - 1;
+        V3 ee; M3 eR; ee_pose(sh, ee, eR);
+        const M3 Rcf = q_to_m(quat_from_euler(0, -PIH_PI, PIH_PI / 2 + sh.S[PIH_S_ATTACH_QZ]));
+        const M3 Rc = mul(ldm(sh.a.LR[L]), Rcf);
+        M3 eRt; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) eRt.m[3 * r + c] = eR.m[3 * c + r];
+        const Q4 qe = m_to_q(mul(Rc, eRt));
+        const V3 xyz = mk(qe.x, qe.y, qe.z);
+        const real sn = norm(xyz); real ang = 2 * (real)atan2(sn, qe.w);
+        if (ang > PIH_PI) ang -= 2 * PIH_PI;
+        const V3 th = sn > (real)1e-12 ? (ang / sn) * xyz : mk(0, 0, 0);
+        emit(slot, L, PIH_EE_PARENT, 2001, th, mk(1, 0, 0), 0, (real)-2);
       }
     });
     nca += w.alloc_count() - before;
@@ -671,7 +694,8 @@ static_assert(NROWC >= 144, "scratch of the inward sweep aliases r_lam");
 // (either may be -1), or a unit joint impulse on the joint of link jm.  Writes the arm part (9) and pipe part (29)
 // of W = M^-1 J^T and returns J W (the inverse effective mass of the row).
 struct RowOut { real* wa; real* wp; };
-PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, RowOut out, V3* dvp_out = nullptr) {
+PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, RowOut out, V3* dvp_out = nullptr, bool ang = false) {
+  // ang: the row is ANGULAR (attach weld): a unit torque `dir` on la, `-dir` on lb; the measured response is the relative angular velocity
   real jw = 0; V3 dvp = mk(0, 0, 0);
   bool arm = (la >= 0 && la < ANL) || (lb >= 0 && lb < ANL) || (jm >= 0 && jm < ANL);
   bool obj = (la >= ANL) || (lb >= ANL) || (jm >= ANL);
@@ -681,8 +705,8 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
     for (int L = 0; L < ANL; L++) { Qa[L] = mk(0, 0, 0); Ql[L] = mk(0, 0, 0); }
 #pragma unroll
     for (int L = ANL - 1; L >= 0; L--) {
-      if (L == la) { Qa[L] = Qa[L] + cross(p - ld3(sh.LO[L]), dir); Ql[L] = Ql[L] + dir; }
-      if (L == lb) { Qa[L] = Qa[L] - cross(p - ld3(sh.LO[L]), dir); Ql[L] = Ql[L] - dir; }
+      if (L == la) { Qa[L] = Qa[L] + (ang ? dir : cross(p - ld3(sh.LO[L]), dir)); Ql[L] = Ql[L] + (ang ? mk(0, 0, 0) : dir); }
+      if (L == lb) { Qa[L] = Qa[L] - (ang ? dir : cross(p - ld3(sh.LO[L]), dir)); Ql[L] = Ql[L] - (ang ? mk(0, 0, 0) : dir); }
       V3 a = ld3(sh.LA[L]);
       constexpr int JT[ANL] = {0, 0, 0, 0, 0, 0, 0, 1, 1};
       constexpr int PAR[ANL] = {-1, 0, 1, 2, 3, 4, 5, 6, 6};
@@ -706,8 +730,8 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
       if (JT[L] == 0) { dw[L] = aa + dq * a; dvv[L] = ll; } else { dw[L] = aa; dvv[L] = ll + dq * a; }
       out.wa[L] = dq;
       if (L == jm) jw += dq;
-      if (L == la) dvp = dvp + (dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
-      if (L == lb) dvp = dvp - (dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
+      if (L == la) dvp = dvp + (ang ? dw[L] : dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
+      if (L == lb) dvp = dvp - (ang ? dw[L] : dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
     }
   }
   if (obj && out.wp) {
@@ -715,8 +739,8 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
 #pragma unroll
     for (int j = ONL - 1; j >= 0; j--) {
       const int L = ANL + j;
-      if (L == la) { Qa = Qa + cross(p - ld3(sh.LO[L]), dir); Ql = Ql + dir; }
-      if (L == lb) { Qa = Qa - cross(p - ld3(sh.LO[L]), dir); Ql = Ql - dir; }
+      if (L == la) { Qa = Qa + (ang ? dir : cross(p - ld3(sh.LO[L]), dir)); Ql = Ql + (ang ? mk(0, 0, 0) : dir); }
+      if (L == lb) { Qa = Qa - (ang ? dir : cross(p - ld3(sh.LO[L]), dir)); Ql = Ql - (ang ? mk(0, 0, 0) : dir); }
       if (j > 0) {
         V3 a = ld3(sh.LA[L]);
         real u = (L == jm ? (real)1 : (real)0) + dot(a, Qa);
@@ -735,8 +759,8 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
       x[i] = s; }
     V3 dw = mk(x[0], x[1], x[2]), dvv = mk(x[3], x[4], x[5]);
     out.wp[0] = dvv.x; out.wp[1] = dvv.y; out.wp[2] = dvv.z; out.wp[3] = dw.x; out.wp[4] = dw.y; out.wp[5] = dw.z;
-    if (ANL == la) dvp = dvp + (dvv + cross(dw, p - ld3(sh.LO[ANL])));
-    if (ANL == lb) dvp = dvp - (dvv + cross(dw, p - ld3(sh.LO[ANL])));
+    if (ANL == la) dvp = dvp + (ang ? dw : dvv + cross(dw, p - ld3(sh.LO[ANL])));
+    if (ANL == lb) dvp = dvp - (ang ? dw : dvv + cross(dw, p - ld3(sh.LO[ANL])));
 #pragma unroll
     for (int j = 1; j < ONL; j++) {
       const int L = ANL + j;
@@ -745,8 +769,8 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
       dw = dw + dq * ld3(sh.LA[L]); dvv = ll;
       out.wp[5 + j] = dq;
       if (L == jm) jw += dq;
-      if (L == la) dvp = dvp + (dvv + cross(dw, p - ld3(sh.LO[L])));
-      if (L == lb) dvp = dvp - (dvv + cross(dw, p - ld3(sh.LO[L])));
+      if (L == la) dvp = dvp + (ang ? dw : dvv + cross(dw, p - ld3(sh.LO[L])));
+      if (L == lb) dvp = dvp - (ang ? dw : dvv + cross(dw, p - ld3(sh.LO[L])));
     }
   }
   if (dvp_out) *dvp_out = dvp;   // relative velocity change at the contact point per unit impulse along dir
@@ -778,6 +802,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
       const bool ismotor = g < NMOT;
       const int row = ismotor ? 0 : g - NMOT, c = row / 3, k = row - 3 * c;
       int la = -1, lb = -1, jm = -1;
+      bool ang = false;
       V3 p = mk(0, 0, 0), dir = mk(0, 0, 0);
       RowOut o; o.wa = nullptr; o.wp = nullptr;
       if (ismotor) {
@@ -785,6 +810,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
         if (g < 9) o.wa = wma_row(sh, g); else o.wp = wmp_row(sh, g - 9);
       } else {
         la = sh.c_la[c]; lb = sh.c_lb[c];
+        ang = sh.c_mu[c] < (real)-1.5;                          // angular rows of the attach weld (p holds the rotation-vector error)
         V3 n = ld3(sh.c_n[c]); p = ld3(sh.c_p[c]);
         V3 t1, t2; plane_space(n, t1, t2);
         dir = k == 0 ? n : (k == 1 ? t1 : t2);
@@ -796,7 +822,7 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
         wr[ND] = 0;
       }
       V3 dvp;
-      const real jw = response(sh, la, lb, p, dir, jm, o, &dvp);
+      const real jw = response(sh, la, lb, p, dir, jm, o, &dvp, ang);
       const real di = (real)1 / jw;
       if (ismotor) {
         const int d = link_dof(jm);
@@ -804,20 +830,21 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
         if (g < 9) sh.lrec[g][2] = jw;
       } else {
         real* R = crec_of(sh, ov, c);
-        V3 vr = point_vel(sh, la, p);
-        if (lb >= 0) vr = vr - point_vel(sh, lb, p);
+        V3 vr = ang ? ld3(sh.VW[la]) : point_vel(sh, la, p);
+        if (lb >= 0) vr = vr - (ang ? ld3(sh.VW[lb]) : point_vel(sh, lb, p));
         real ju = dot(dir, vr);
         real lam = 0, rhs;
         if (k == 0) {
           real pen = sh.c_depth[c] + P.slop;
           real vb = pen > 0 ? -pen / dt : -P.erp * pen / dt;
           if (sh.c_mu[c] < 0) vb = -P.erp * sh.c_depth[c] / dt;   // attach: close the gap with ERP, both signs allowed
+          if (ang) vb = -P.erp * dot(p, dir) / dt;                // weld: rotate the child frame back onto the parent frame
           rhs = (vb - ju) * di;
           int ncache = (int)sh.S[PIH_S_CACHE_N]; real key = (real)sh.c_key[c];
           for (int q = 0; q < ncache; q++) if (sh.S[PIH_S_CACHE_KEY + q] == key) { lam = P.warm * sh.S[PIH_S_CACHE_LAMBDA + q]; break; }
           const bool bil = sh.c_mu[c] < 0;
-          R[0] = p.x; R[1] = p.y; R[2] = p.z; R[3] = bil ? -PIH_BIG : (real)0; R[4] = bil ? PIH_BIG : (real)0; R[5] = sh.c_mu[c]; R[6] = 0; R[7] = 0;
-        } else rhs = -ju * di;
+          R[0] = p.x; R[1] = p.y; R[2] = p.z; R[3] = bil ? -PIH_BIG : (real)0; R[4] = bil ? PIH_BIG : (real)0; R[5] = sh.c_mu[c]; R[6] = ang ? (real)1 : (real)0; R[7] = 0;
+        } else rhs = ((ang ? -P.erp * dot(p, dir) / dt : (real)0) - ju) * di;
         R[8 + 4 * k] = dir.x; R[9 + 4 * k] = dir.y; R[10 + 4 * k] = dir.z; R[11 + 4 * k] = di;
         R[20 + k] = rhs;
         if (k < 2) { R[26 + 3 * k] = dvp.x; R[27 + 3 * k] = dvp.y; R[28 + 3 * k] = dvp.z; }
@@ -862,11 +889,12 @@ PIH_HD bool is_anc(int L, int X) {   // is the joint of link L on the path from 
   if (L < ANL) return X < ANL && ((L <= 6 && L <= X) || L == X);
   return X >= ANL && L <= X;
 }
-PIH_HD real jac_entry(const DofGeom& g, int la, int lb, V3 p, V3 dir) {
+PIH_HD real jac_entry(const DofGeom& g, int la, int lb, V3 p, V3 dir, bool ang = false) {
   if (g.kind == 2) return 0;
   real s = (is_anc(g.L, la) ? (real)1 : (real)0) - (is_anc(g.L, lb) ? (real)1 : (real)0);
   if (s == 0) return 0;
-  real v = g.kind == 0 ? dot(dir, cross(g.a, p - g.o)) : dot(dir, g.a);
+  // angular row (attach weld): d . omega -> the axis of a revolute-like DOF, nothing from a prismatic-like one
+  real v = ang ? (g.kind == 0 ? dot(dir, g.a) : (real)0) : (g.kind == 0 ? dot(dir, cross(g.a, p - g.o)) : dot(dir, g.a));
   return s * v;
 }
 

@@ -279,13 +279,13 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
     const bool ismotor = lane < NMOT;
     const int row = ismotor ? 0 : lane - NMOT, c = row / 3, k = row - 3 * c;
     const bool live = !ismotor && c < nc;
-    int la = -1, lb = -1; V3 p = mk(0, 0, 0), dir = mk(0, 0, 0);
-    if (live) { la = sh.c_la[c]; lb = sh.c_lb[c]; const real* R = sh.b.crec[c]; p = ld3(R); dir = ld3(R + 8 + 4 * k); }
+    int la = -1, lb = -1; V3 p = mk(0, 0, 0), dir = mk(0, 0, 0); bool ang = false;
+    if (live) { la = sh.c_la[c]; lb = sh.c_lb[c]; const real* R = sh.b.crec[c]; p = ld3(R); dir = ld3(R + 8 + 4 * k); ang = R[6] != 0; }
     const int md = lane < 9 ? lane : 15 + (lane - 9);
 #pragma unroll
     for (int d = 0; d < ND; d++) {
       const DofGeom g = dof_geom(sh, d);
-      const real jc = live ? jac_entry(g, la, lb, p, dir) : (real)0;
+      const real jc = live ? jac_entry(g, la, lb, p, dir, ang) : (real)0;
       J[d] = ismotor ? (d == md ? (real)1 : (real)0) : jc;
       __asm__ volatile("" : "+v"(J[d]) :: "memory");     // one DOF at a time (same reason as for the columns of A below)
     }
@@ -518,8 +518,10 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
   // ae = 0, mp = axis; unused lane: both 0) -- no per-contact select
   const V3 ae = g.kind == 0 ? g.a : mk(0, 0, 0), mp = g.kind == 1 ? g.a : mk(0, 0, 0);
   real du = 0;
+  int ang_c = -1;
   for (int c = 0; c < nc; c++) {
     int la = sh.c_la[c], lb = sh.c_lb[c];
+    if (sh.c_mu[c] < (real)-1.5) ang_c = c;
     int sgn = g.kind != 2 ? (int)is_anc(g.L, la) - (int)is_anc(g.L, lb) : 0;
     unsigned code = (unsigned)sgn & 3u;
     if (c < 16) sg0 |= code << (2 * c); else if (c < 32) sg1 |= code << (2 * (c - 16)); else sg2 |= code << (2 * (c - 32));
@@ -528,6 +530,7 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
       du += (c < CL ? sh.b.Wp[3 * c][dw] : ov.base[(size_t)(3 * (c - CL)) * WPS + dw]) * l;
     }
   }
+  const int ang_cs = __builtin_amdgcn_readfirstlane(ang_c);
   // one PGS iteration; returns true when every row moved by less than its threshold
   auto iterate = [&]() __attribute__((always_inline)) -> bool {
     // Early exit (Bullet's least-squares residual test, max over rows of (d lambda / dinv)^2 <= resid) as |d lambda| >
@@ -592,6 +595,8 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
       return r;
     };
     auto block = [&](int c, unsigned sgw, const CRec& r, real* R, bool in_lds) __attribute__((always_inline)) {
+      // (the angular rows of the attach weld -- at most one such contact, scripted mode only, index ang_c -- take the DOF's axis
+      //  itself as Jacobian column instead of axis x lever arm: one scalar compare per contact)
       // q0 = p.xyz, lo_n | q1 = hi_floor, mu, -, - | q2 = n, dinv_n | q3 = t1, dinv_t1 | q4 = t2, dinv_t2
       // q5 = rhs n,t1,t2, G[t1][n] | q6 = G[t2][n], G[t2][t1], lam_n, lam_t1 | q7 = lam_t2, ...
       // (lo_n = 0 / -BIG and hi_floor = 0 / +BIG make the attach rows bilateral without a select)
@@ -599,7 +604,8 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
       const V3 pr = mk(r.q[0].x - g.o.x, r.q[0].y - g.o.y, r.q[0].z - g.o.z);
       const real mu = r.q[1].y;
       const real sdu = (real)(int)__builtin_amdgcn_sbfe(sgw, 2u * (unsigned)(c & 15), 2u) * du;
-      const V3 cv = mk(__builtin_fmaf(ae.y, pr.z, __builtin_fmaf(-ae.z, pr.y, mp.x)), __builtin_fmaf(ae.z, pr.x, __builtin_fmaf(-ae.x, pr.z, mp.y)), __builtin_fmaf(ae.x, pr.y, __builtin_fmaf(-ae.y, pr.x, mp.z)));
+      V3 cv = mk(__builtin_fmaf(ae.y, pr.z, __builtin_fmaf(-ae.z, pr.y, mp.x)), __builtin_fmaf(ae.z, pr.x, __builtin_fmaf(-ae.x, pr.z, mp.y)), __builtin_fmaf(ae.x, pr.y, __builtin_fmaf(-ae.y, pr.x, mp.z)));
+      if (__builtin_expect(c == ang_cs, 0)) cv = ae;
       real jd0 = sdu * dot(mk(r.q[2].x, r.q[2].y, r.q[2].z), cv), jd1 = sdu * dot(mk(r.q[3].x, r.q[3].y, r.q[3].z), cv), jd2 = sdu * dot(mk(r.q[4].x, r.q[4].y, r.q[4].z), cv);
       // materialise the products: otherwise fast-math folds the multiply into the first reduction step as mul + mov_dpp + fmac
       // (3 instructions per value) instead of mul + v_add_f32_dpp (2)

@@ -188,7 +188,7 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
         else if (k > 0) { real tot = sh.r_lam[3 * c]; if (!(tot > 0)) continue; hi = R[5] * tot; lo = -hi; }
         V3 dir = ld3(R + 8 + 4 * k);
         real jd = 0;
-        for (int d = 0; d < ND; d++) jd += jac_entry(geo[d], sh.c_la[c], sh.c_lb[c], p, dir) * du[d];
+        for (int d = 0; d < ND; d++) jd += jac_entry(geo[d], sh.c_la[c], sh.c_lb[c], p, dir, R[6] != 0) * du[d];
         real di = R[11 + 4 * k];
         real dl = R[20 + k] - jd * di, sum = sh.r_lam[row] + dl;
         if (sum < lo) { dl = lo - sh.r_lam[row]; sum = lo; } else if (sum > hi) { dl = hi - sh.r_lam[row]; sum = hi; }

@@ -126,3 +126,81 @@ def test_facade_scripted_step_returns_camera_image_and_labels(oracle_mod):
     rv = oracle_mod.rotate_vector([0, o.get_state()[0, 90], 0], tip[3:7])
     assert abs(np.arctan2(rv[1], rv[0]) - a) < 1e-9
     assert np.array_equal(o.render(300, 300)[0], img)
+
+
+def _attach_frame_error(oracle_mod, s):
+    """angle [rad] between the parent frame (link 11) and the child frame R_link R_cf of the attach constraint"""
+    O = oracle_mod
+    def q2m(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w], [2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w],
+                         [2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y]])
+    out = []
+    for i in range(s.shape[0]):
+        Ree = q2m(O.fk_arm(s[i, 0:9], 9)[1])
+        Rcf = q2m(O.quat_from_euler([0, -np.pi, np.pi / 2 + s[i, 113]]))
+        out.append((Ree, Rcf))
+    return out
+
+
+def test_attach_weld_keeps_the_child_frame_on_the_parent_frame(oracle_mod):
+    """p7 as a 6-row WELD honouring childFrameOrientation (envs/peg_in_hole.py:99-104): through states 4..6 the child frame
+    R_link R_cf stays on the parent frame (link 11) to within a few degrees, which the 3-row ball joint (attach_ball = 1) does not
+    enforce; the reward = 1 fraction (peg tip within 5 cm of the hole when the insert state ends) is reported for both."""
+    O = oracle_mod
+    N = 16
+    res = {}
+    for ball in (0, 1):
+        o = O.Oracle(N, mode=1, dv=0.05, omp=True, attach_ball=ball)
+        a = np.zeros((N, 4))
+        errs = []; hit = None
+        for t in range(2105):
+            obs, rew, _ = o.step(a)
+            if t >= 1500 and t % 20 == 0:
+                s = o.get_state(); tips = o.tip_pose()
+                keys = [int(k) for k in o.debug_contacts(0)[:, 10]]
+                assert (2001 in keys) == (ball == 0) and 2000 in keys
+                for i, (Ree, Rcf) in enumerate(_attach_frame_error(O, s)):
+                    x, y, z, w = tips[i, 3:7]
+                    Rl = np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w], [2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w],
+                                   [2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y]])
+                    E = Rl @ Rcf @ Ree.T
+                    errs.append(np.arccos(np.clip((np.trace(E) - 1) / 2, -1, 1)))
+            hit = rew
+        res[ball] = (np.median(errs), np.percentile(errs, 90), hit.mean())
+        assert np.isfinite(o.get_state()).all()
+    print("attach weld: frame error median %.3f rad (p90 %.3f), success %.2f | ball joint: median %.3f rad (p90 %.3f), success %.2f" % (*res[0], *res[1]))
+    # not tight: the fingers hold the link in ITS orientation while the reference's childFrameOrientation uses the quaternion's z
+    # component where a yaw angle was meant (a mismatch of up to ~0.5 rad about z), and ERP is 0.2 per step
+    assert res[0][0] < 0.6 and res[0][0] < 0.35 * res[1][0]
+    assert res[0][2] >= 0.3
+
+
+def test_hand_spheres_stop_the_pipe(oracle_mod):
+    """Arm collision spheres vs the pipe (enable_arm_collision bit 1): a straight pipe dropped across the wrist sphere (link 5
+    origin, r = 5.5 cm) comes to rest on it; with the bit off it falls through to the table."""
+    O = oracle_mod
+    REST = np.array([0, -0.215, -np.pi / 3, -2.57, 0, 2.356, 2.356, 0, 0])
+    wrist = O.fk_arm(REST, 5)[0]
+    p0 = O.fk_arm(REST, 9)[0]
+    zs = {}
+    for ac in (3, 1):
+        o = O.Oracle(1, enable_arm_collision=ac, enable_self_collision=0)
+        s = o.get_state()
+        s[0, 31:54] = 0                                           # straight pipe along +y, centred over the wrist sphere
+        s[0, 18:21] = [wrist[0], wrist[1] - 0.65, wrist[2] + 0.055 + 0.01 + 0.03]
+        s[0, 21:25] = [0, 0, 0, 1]; s[0, 25:31] = 0
+        o.set_state(s)
+        a = np.array([[p0[0], p0[1], p0[2], 0.0]])                 # hold the arm where it is
+        seen = 0; dmin = 1.0
+        for t in range(40):
+            o.step(a)
+            c = o.debug_contacts(0); hand = c[c[:, 10] >= 5000]
+            seen += len(hand) > 0
+            if len(hand):
+                dmin = min(dmin, hand[:, 8].min())
+        st = o.get_state()[0]
+        zs[ac] = (st[20], seen, dmin)
+    print("pipe dropped on the wrist sphere: base z after 40 steps %.3f with arm-vs-pipe spheres (%d steps in contact), %.3f without" % (zs[3][0], zs[3][1], zs[1][0]))
+    assert zs[3][1] > 20 and zs[3][2] > -2e-3                      # carried by the sphere without sinking into it (it see-saws and will slide off eventually)
+    assert zs[1][1] == 0 and zs[1][0] < zs[3][0] - 0.03            # falls freely without the spheres
