@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--task", default="peg-in-hole", choices=["peg-in-hole", "random-fly"], help="random-fly = BASELINE configs[4]: UR5 + free-flying object, args=['Banana', 1/120.]")
     ap.add_argument("--mode", default="action", choices=["action", "scripted"], help="action = panda_execute per step (headline); scripted = the reference's grasp-and-insert state machine")
     ap.add_argument("--solver-path", type=int, default=0, help="1 = DOF-space PGS for every env (A/B against the default row-space path for <= 10 contacts)")
+    ap.add_argument("--schedule", type=int, default=1, help="dispatch order: 1 longest-job-first (default), 0 env order, 2 partner-aware (experimental)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (1-GPU box, gloo backend)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / collective / JSON plumbing only, no env and no GPU (CPU test of the N>1 path)")
@@ -248,7 +249,7 @@ def main():
             env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, seed=args.seed, task_id=1, dt=1.0 / 120.0, max_episode_steps=480, contact_margin=0.02)
         else:
             mode_kw = dict(mode=1, dv=0.05) if args.mode == "scripted" else {}
-            env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, max_episode_steps=2227, seed=args.seed, solver_path=args.solver_path, **mode_kw)
+            env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, max_episode_steps=2227, seed=args.seed, solver_path=args.solver_path, schedule=args.schedule, **mode_kw)
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         pool = min(args.steps + args.warmup + args.preroll, 1024)
         actions = torch.rand(pool, n, adim, device=dev, generator=gen) * 2 - 1       # resident in HBM before the timed region
