@@ -63,19 +63,19 @@ void emul_step(void* h, const double* actions, double* obs, double* reward, unsi
     Ovf ov; ov.base = ovfbuf;
     step_env(w, sh, e->P, ov, i, a, o, &r, &d, &e->dbg[(size_t)i * PIH_DEBUG_WORDS]);
     memcpy(S, sh.S, sizeof(real) * PIH_STATE_WORDS);
-    for (int k = 0; k < 5; k++) obs[5 * i + k] = o[k];
-    reward[i] = r; done[i] = d;
+    for (int k = 0; k < 5; k++) obs[5 * i + k] = (double)o[k];
+    reward[i] = (double)r; done[i] = d;
   }
 }
-void emul_get_state(void* h, double* out) { Emul* e = (Emul*)h; for (size_t i = 0; i < e->state.size(); i++) out[i] = e->state[i]; }
+void emul_get_state(void* h, double* out) { Emul* e = (Emul*)h; for (size_t i = 0; i < e->state.size(); i++) out[i] = (double)e->state[i]; }
 void emul_set_state(void* h, const double* in) { Emul* e = (Emul*)h; for (size_t i = 0; i < e->state.size(); i++) e->state[i] = (real)in[i]; }
-void emul_get_debug(void* h, double* out) { Emul* e = (Emul*)h; for (size_t i = 0; i < e->dbg.size(); i++) out[i] = e->dbg[i]; }
+void emul_get_debug(void* h, double* out) { Emul* e = (Emul*)h; for (size_t i = 0; i < e->dbg.size(); i++) out[i] = (double)e->dbg[i]; }
 void emul_ik(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout) {
   Params P = make_params(c); Serial w; real ikT[7][12];
   real q[9], qo[7]; for (int i = 0; i < 9; i++) q[i] = (real)q0[i];
   Q4 tq; tq.x = (real)tquat[0]; tq.y = (real)tquat[1]; tq.z = (real)tquat[2]; tq.w = (real)tquat[3];
   ik_chain<PandaChain>(w, ikT, P, q, mk((real)tpos[0], (real)tpos[1], (real)tpos[2]), tq, qo);
-  for (int i = 0; i < 7; i++) qout[i] = qo[i];
+  for (int i = 0; i < 7; i++) qout[i] = (double)qo[i];
   qout[7] = q0[7]; qout[8] = q0[8];
 }
 void emul_ik_ur5(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout) {
@@ -83,7 +83,7 @@ void emul_ik_ur5(const pih_config* c, const double* q0, const double* tpos, cons
   real q[6], qo[6]; for (int i = 0; i < 6; i++) q[i] = (real)q0[i];
   Q4 tq; tq.x = (real)tquat[0]; tq.y = (real)tquat[1]; tq.z = (real)tquat[2]; tq.w = (real)tquat[3];
   ik_chain<Ur5Chain>(w, ikT, P, q, mk((real)tpos[0], (real)tpos[1], (real)tpos[2]), tq, qo);
-  for (int i = 0; i < 6; i++) qout[i] = qo[i];
+  for (int i = 0; i < 6; i++) qout[i] = (double)qo[i];
 }
 
 // ---- 'random-fly' task (pih_fly.h): the same per-lane scalar code the GPU runs, one env after the other
@@ -117,11 +117,28 @@ void emul_fly_step(void* h, const double* actions, double* obs, double* reward, 
     for (int k = 0; k < 6; k++) a[k] = (real)actions[6 * i + k];
     fly::LaneMem mem; mem.p = lanemem; mem.stride = 1;
     fly::step_env(&e->state[(size_t)i * PIH_FLY_STATE_WORDS], e->P, e->P.env0 + i, a, o, &r, &d, mem, &e->dbg[(size_t)i * PIH_DEBUG_WORDS]);
-    for (int k = 0; k < 6; k++) obs[6 * i + k] = o[k];
-    reward[i] = r; done[i] = d;
+    for (int k = 0; k < 6; k++) obs[6 * i + k] = (double)o[k];
+    reward[i] = (double)r; done[i] = d;
   }
 }
-void emul_fly_get_state(void* h, double* out) { EmulFly* e = (EmulFly*)h; for (size_t i = 0; i < e->state.size(); i++) out[i] = e->state[i]; }
+void emul_fly_get_state(void* h, double* out) { EmulFly* e = (EmulFly*)h; for (size_t i = 0; i < e->state.size(); i++) out[i] = (double)e->state[i]; }
 void emul_fly_set_state(void* h, const double* in) { EmulFly* e = (EmulFly*)h; for (size_t i = 0; i < e->state.size(); i++) e->state[i] = (real)in[i]; }
-void emul_fly_get_debug(void* h, double* out) { EmulFly* e = (EmulFly*)h; for (size_t i = 0; i < e->dbg.size(); i++) out[i] = e->dbg[i]; }
+void emul_fly_get_debug(void* h, double* out) { EmulFly* e = (EmulFly*)h; for (size_t i = 0; i < e->dbg.size(); i++) out[i] = (double)e->dbg[i]; }
+
+// operation counters of the CountedReal build (zeros in the plain builds): [phase 0..15][add, mul, div, sqrt, trans, cmp]
+void emul_flops_reset() {
+#ifdef PIH_COUNT_FLOPS
+  memset(&flop_counters(), 0, sizeof(FlopCounters)); memset(pih::g_phase_flops, 0, sizeof pih::g_phase_flops); pih::g_phase_last = flop_counters();
+#endif
+}
+void emul_flops_get(unsigned long long* out /* [16][6] */, unsigned long long* total /* [6] */) {
+#ifdef PIH_COUNT_FLOPS
+  for (int k = 0; k < 16; k++) for (int j = 0; j < 6; j++) out[6 * k + j] = pih::g_phase_flops[k][j];
+  const FlopCounters& c = flop_counters();
+  total[0] = c.add; total[1] = c.mul; total[2] = c.div; total[3] = c.sqrt_; total[4] = c.trans; total[5] = c.cmp;
+#else
+  for (int k = 0; k < 96; k++) out[k] = 0;
+  for (int j = 0; j < 6; j++) total[j] = 0;
+#endif
+}
 }

@@ -6,6 +6,10 @@
 #include "../../peg_in_hole_gym_amd/csrc/pih_common.h"
 
 namespace pih {
+#ifdef PIH_COUNT_FLOPS
+static uint64_t g_phase_flops[16][6];
+static FlopCounters g_phase_last;
+#endif
 
 struct Wave {
   static constexpr bool controller_inline = true;      // no pre-kernel on the host: the controller runs inside step_env
@@ -13,8 +17,18 @@ struct Wave {
   real du[ND];
   real hWmp[PIH_OBJ_NJ][WMS], hWma[9][9];               // motor response rows (the GPU keeps them in registers)
   void stamp(int) {}
+#ifdef PIH_COUNT_FLOPS
+  void phase_begin() { g_phase_last = flop_counters(); }
+  void phase(int k) {      // attribute the operations since the last mark to phase k (0 fk, 1 motor targets, 2 collide, 3 aba, 4 rows, 5 pgs, 6 integrate, 7 fk2)
+    const FlopCounters c = flop_counters();
+    const uint64_t now[6] = {c.add, c.mul, c.div, c.sqrt_, c.trans, c.cmp}, was[6] = {g_phase_last.add, g_phase_last.mul, g_phase_last.div, g_phase_last.sqrt_, g_phase_last.trans, g_phase_last.cmp};
+    for (int j = 0; j < 6; j++) g_phase_flops[k][j] += now[j] - was[j];
+    g_phase_last = c;
+  }
+#else
   void phase_begin() {}
   void phase(int) {}
+#endif
   int lane() const { return 0; }
   void sync() {}
   template <class F> void par(int n, F f) { for (int i = 0; i < n; i++) f(i); }

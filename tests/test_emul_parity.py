@@ -227,3 +227,24 @@ def test_many_contacts_spill_rows(oracle_mod, prec):
     else:
         assert np.percentile(perr[ok], 50) < 5e-6 and np.percentile(perr[ok], 99) < 1e-4
         assert np.percentile(ferr[ok], 50) < 1e-3 and np.percentile(ferr[ok], 99) < 1e-2
+
+
+def test_operation_counting_build_counts_and_computes_the_same():
+    """tools/count_flops.py's CountedReal build of the algorithm (the source of profiles/flops_latest.json) must compute exactly
+    what the plain fp64 build computes, and report a plausible operation count per env-step."""
+    import ctypes as C, subprocess, os
+    subprocess.check_call(["make", "-C", os.path.dirname(E.__file__), "-s", "count"])
+    N = 4
+    a = E.Emul(N, "f64", seed=3); c = E.Emul(N, "cnt", seed=3)
+    c.L.emul_flops_reset.restype = None
+    c.L.emul_flops_get.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    rng = np.random.default_rng(0)
+    c.L.emul_flops_reset()
+    for t in range(60):
+        act = rng.uniform(-1, 1, (N, 4))
+        a.step(act); c.step(act)
+    np.testing.assert_array_equal(a.get_state(), c.get_state())
+    ph = (C.c_ulonglong * 96)(); tot = (C.c_ulonglong * 6)()
+    c.L.emul_flops_get(ph, tot)
+    per = sum(tot[:5]) / (N * 60)
+    assert 1e5 < per < 3e6 and sum(ph[6 * 5:6 * 5 + 5]) > 0.3 * sum(tot[:5])     # PGS is the bulk

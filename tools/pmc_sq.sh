@@ -8,11 +8,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU"
 P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_BANK_CONFLICT"
+# executed fp32 work (wave-instructions: x 64 lanes = lane-flops, idle and redundant wave-uniform lanes included)
+P3="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM SQ_INSTS_FLAT"
 i=0
-for C in "$P1" "$P2"; do
+for C in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/sq_${TAG}_$i
-  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/sq_${TAG}_$i -- python $R/bench.py --steps 40 --warmup 120 --no-cpu-baseline > $R/gpurun_out/sq_${TAG}_$i.bench.json 2> $R/gpurun_out/sq_${TAG}_$i.err
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/sq_${TAG}_$i -- python $R/bench.py --steps 40 --warmup 20 --no-cpu-baseline > $R/gpurun_out/sq_${TAG}_$i.bench.json 2> $R/gpurun_out/sq_${TAG}_$i.err
 done
 cd $R && python - "$TAG" <<'PY'
 import csv, glob, json, os, sys
@@ -25,6 +27,11 @@ for f in glob.glob("gpurun_out/sq_%s_*/**/*counter_collection.csv" % tag, recurs
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     out[k] = sum(v) / len(v)
+n_envs = 4096
+if "SQ_INSTS_VALU" in out:
+    out["valu_insts_per_env_step"] = out["SQ_INSTS_VALU"] / n_envs
+if all(k in out for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")):
+    out["executed_lane_flop_per_env_step"] = 64 * (out["SQ_INSTS_VALU_ADD_F32"] + out["SQ_INSTS_VALU_MUL_F32"] + 2 * out["SQ_INSTS_VALU_FMA_F32"] + out.get("SQ_INSTS_VALU_TRANS_F32", 0)) / n_envs
 w = out.get("SQ_WAVE_CYCLES")
 if w:
     for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_LDS"):
