@@ -68,10 +68,15 @@ def cpu_baseline(preroll=300, budget_s=25.0):
     fp32 all-cores row.  The sample is sized from a short probe so that the leg stays within ~budget_s."""
     import numpy as np
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     outdir = tempfile.mkdtemp(prefix="pih_oracle_native_")
     p64, p32 = O.build_native(outdir)
+    try:      # libgomp is already in the process (torch): the environment variable alone would come too late
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except Exception:  # noqa: BLE001
+        pass
     rng = np.random.default_rng(1234)
     rows = []
 
@@ -130,10 +135,15 @@ def cpu_baseline_fly(preroll=300, budget_s=20.0):
     """The same for the random-fly task (oracle/pih_fly_oracle.c): fp32 / fp64 all cores, and N = 1 on one thread."""
     import numpy as np
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     outdir = tempfile.mkdtemp(prefix="pih_oracle_native_")
     p64, p32 = O.build_native(outdir)
+    try:      # libgomp is already in the process (torch): the environment variable alone would come too late
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except Exception:  # noqa: BLE001
+        pass
     rng = np.random.default_rng(1234)
     rows = []
 
@@ -165,6 +175,14 @@ def cpu_baseline_fly(preroll=300, budget_s=20.0):
     return {"value": main["value"], "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d steps after a %d-step pre-roll, fp32 build of the CPU restatement in oracle/pih_fly_oracle.c (NOT PyBullet), "
                       "gcc -O3 -march=native, OpenMP over envs on all %d cores" % (n, timed, preroll, cores), "rows": rows}
+
+
+def usable_cores():
+    """CPU cores this process may run on (the box's share), not the host's total"""
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        return os.cpu_count() or 1
 
 
 def _free_port():
