@@ -268,6 +268,28 @@ PIH_HD void row16_sum3(real& a, real& b, real& c) {
 // row updates as Bullet (per arm joint: motor, lower, upper limit; the 23 pipe motors; per contact: normal, dir1, dir2).  The DOF
 // velocities are recovered at the end as du = sum_i W_i lambda_i.  The arm-row and pipe-row columns are disjoint (A[arm][pipe
 // motor] = 0), so the motor chain runs on two accumulators for ILP exactly like the DOF-space chain.
+// The iteration loop of both solvers.  Bullet's early exit (largest squared row residual <= 1e-7) is evaluated in the first four
+// iterations -- where it actually fires: envs in free flight converge in two -- and after that in every 8th iteration and in the
+// last one; in between the body runs without the per-row compare (one v_cmp + one scalar OR per row, ~15 % of a row update).  An
+// env that would have met the threshold between two checks performs at most 7 extra iterations whose updates are all below the
+// threshold; with residual_threshold = 0 (every parity test) nothing changes.  The unchecked body is instantiated twice per trip:
+// the multipliers are loop-carried, and with a single copy every new value is moved back into the register the loop header expects.
+template <class FC, class FN> PIH_HD int pgs_iteration_loop(int iters, FC checked, FN unchecked) {
+  int it = 0;
+  // iterations 1..4 with the test
+  while (it < iters && it < 4) { it++; if (checked()) return it; }
+  // then groups of eight: seven without, one with (the last iteration always with)
+  while (it < iters) {
+    const int stop = it + 7 < iters - 1 ? it + 7 : iters - 1;
+    while (it < stop) {
+      it++; unchecked();
+      if (it >= stop) break;
+      it++; unchecked();
+    }
+    it++; if (checked()) return it;
+  }
+  return it;
+}
 constexpr int FR = NMOT + 3 * MERGED_CONTACTS;
 PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
   const int nc = __builtin_amdgcn_readfirstlane(sh.nc);
@@ -355,6 +377,8 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       const real tol = (real)1e-4 * ((real)1 + absr(vt) + absr(uj) + absr(vlo) + absr(vhi));
       skip7 = skip7 && (vt - vlo > tol) && (-vhi - vt > tol);
     }
+    // only with the huge impulse bound of the action-mode controller (1e5 dt): the scripted controller's 1200 dt does clamp
+    skip7 = skip7 && sh.mrec[0][3] >= (real)100;
     skip7 = __builtin_amdgcn_readfirstlane((int)skip7) != 0;
   }
   // ---- multipliers: wave-uniform values in VGPRs
@@ -372,7 +396,8 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
     for (int c = 0; c < MERGED_CONTACTS; c++)
       if (c < nc) { v += A[NMOT + 3 * c] * sh.r_lam[3 * c]; if (lane == 0) { real* R = sh.b.crec[c]; R[16] = sh.r_lam[3 * c]; R[17] = 0; R[18] = 0; } }   // warm start
     unsigned long long clamped = 0;
-    auto iterate = [&]() __attribute__((always_inline)) -> bool {
+    auto iterate = [&](auto CHECKTAG) __attribute__((always_inline)) -> bool {
+      constexpr bool CHECK = decltype(CHECKTAG)::value;     // evaluate the early-exit test in this iteration? (see pgs_iteration_checks)
       unsigned long long busy = 0;
       __asm__ volatile("" ::: "memory");      // keep the row constants in LDS (see pgs(): LICM would hoist and spill them)
       constexpr int PF = 4;
@@ -401,19 +426,19 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
           real sum = lam_a[j] + (rhs - dj * di);
           sum = med3_(sum, -lim, lim);
           const real dl = sum - lam_a[j]; lam_a[j] = sum;
-          busy |= __ballot(absr(dl) > thr);
+          if (CHECK) busy |= __ballot(absr(dl) > thr);
           if (FULL || j >= 7) {
             dj += dl * wjj;
             real s2 = lam_lo[j] + (lor - dj * di); s2 = max_(s2, (real)0);
             const real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
-            busy |= __ballot(absr(d2) > thr);
+            if (CHECK) busy |= __ballot(absr(d2) > thr);
             dj += d2 * wjj;
             real s3 = lam_hi[j] + (hir + dj * di); s3 = max_(s3, (real)0);
             const real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
-            busy |= __ballot(absr(d3) > thr);
+            if (CHECK) busy |= __ballot(absr(d3) > thr);
             va += A[j] * (dl + d2 - d3);
           } else {
-            clamped |= __ballot(absr(sum) >= lim);
+            if (CHECK) clamped |= __ballot(absr(sum) >= lim);     // watched in the checked iterations (a multiplier at its bound stays there)
             va += A[j] * dl;
           }
         }
@@ -422,7 +447,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
         real sum = lam_p[j] + (rhs - dj * di);
         sum = med3_(sum, -lim, lim);
         const real dl = sum - lam_p[j]; lam_p[j] = sum;
-        busy |= __ballot(absr(dl) > thr);
+        if (CHECK) busy |= __ballot(absr(dl) > thr);
         vp += A[9 + j] * dl;
       }
       v = (va + vp) - v;
@@ -441,28 +466,23 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
         real s0 = l0 + (q0.x - vn * q2.y);
         s0 = max_(s0, q1.w);
         const real dl0 = s0 - l0;
-        busy |= __ballot(absr(dl0) > q3.x);
+        if (CHECK) busy |= __ballot(absr(dl0) > q3.x);
         real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
         if (rdlane(s0, 0) > 0 || rdlane(q1.z, 0) < 0) {   // wave-uniform (Bullet skips the friction rows of an unloaded contact)
           const real hi = max_(q1.z * s0, q2.x);
           vt1 += q0.w * dl0;
           s1 = l1 + (q0.y - vt1 * q2.z); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
-          busy |= __ballot(absr(dl1) > q3.y);
+          if (CHECK) busy |= __ballot(absr(dl1) > q3.y);
           vt2 += q1.x * dl0 + q1.y * dl1;
           s2 = l2 + (q0.z - vt2 * q2.w); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
-          busy |= __ballot(absr(dl2) > q3.z);
+          if (CHECK) busy |= __ballot(absr(dl2) > q3.z);
         }
         if (lane == 0) { Rw[16] = s0; Rw[17] = s1; Rw[18] = s2; }
         v += A[g0] * dl0 + A[g0 + 1] * dl1 + A[g0 + 2] * dl2;
       }
-      return busy == 0;
+      return CHECK && busy == 0;
     };
-    it = 0;
-    while (it < P.iters) {
-      it++; if (iterate()) break;
-      if (it >= P.iters) break;
-      it++; if (iterate()) break;
-    }
+    it = pgs_iteration_loop(P.iters, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
     return clamped != 0;
   };
   if (!skip7 || solve(std::false_type{})) solve(std::true_type{});
@@ -532,7 +552,8 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
   }
   const int ang_cs = __builtin_amdgcn_readfirstlane(ang_c);
   // one PGS iteration; returns true when every row moved by less than its threshold
-  auto iterate = [&]() __attribute__((always_inline)) -> bool {
+  auto iterate = [&](auto CHECKTAG) __attribute__((always_inline)) -> bool {
+    constexpr bool CHECK = decltype(CHECKTAG)::value;     // evaluate the early-exit test in this iteration? (see pgs_iteration_loop)
     // Early exit (Bullet's least-squares residual test, max over rows of (d lambda / dinv)^2 <= resid) as |d lambda| >
     // sqrt(resid) dinv per row: one v_cmp into a wave mask + a scalar OR per row instead of an FMA and a max.  Bit 32 is read:
     // the motor chain is wave-uniform and the contact chain is valid in lanes 32..47.
@@ -560,15 +581,15 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
         real sum = lam_a[j] + (rhs - dj * di);
         sum = med3_(sum, -lim, lim);
         real dl = sum - lam_a[j]; lam_a[j] = sum;
-        busy |= __ballot(absr(dl) > thr);
+        if (CHECK) busy |= __ballot(absr(dl) > thr);
         dj += dl * wjj;
         real s2 = lam_lo[j] + (lor - dj * di); s2 = max_(s2, (real)0);
         real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
-        busy |= __ballot(absr(d2) > thr);
+        if (CHECK) busy |= __ballot(absr(d2) > thr);
         dj += d2 * wjj;
         real s3 = lam_hi[j] + (hir + dj * di); s3 = max_(s3, (real)0);
         real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
-        busy |= __ballot(absr(d3) > thr);
+        if (CHECK) busy |= __ballot(absr(d3) > thr);
         tot_a = dl + d2 - d3;
       }
       // pipe joint motor j (DOF 15 + j)
@@ -577,7 +598,7 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
       real sum = lam_p[j] + (rhs - dj * di);
       sum = med3_(sum, -lim, lim);
       real dl = sum - lam_p[j]; lam_p[j] = sum;
-      busy |= __ballot(absr(dl) > thr);
+      if (CHECK) busy |= __ballot(absr(dl) > thr);
       du += mw.w[j] * (armlane ? tot_a : dl);
     }
     // one exact 3x3 Gauss-Seidel block per contact.  The body is instantiated twice so that the LDS-resident contacts
@@ -617,16 +638,16 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
       real s0 = l0 + (r.q[5].x - jd0 * di0);
       s0 = max_(s0, r.q[0].w);
       real dl0 = s0 - l0;
-      busy |= __ballot(absr(dl0) > r.q[7].y);
+      if (CHECK) busy |= __ballot(absr(dl0) > r.q[7].y);
       real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
       if (rdlane(s0, 32) > 0 || rdlane(mu, 32) < 0) {   // wave-uniform branch (Bullet skips the friction rows of an unloaded contact)
         real hi = max_(mu * s0, r.q[1].x);
         jd1 += r.q[5].w * dl0;
         s1 = l1 + (r.q[5].y - jd1 * di1); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
-        busy |= __ballot(absr(dl1) > r.q[7].z);
+        if (CHECK) busy |= __ballot(absr(dl1) > r.q[7].z);
         jd2 += r.q[6].x * dl0 + r.q[6].y * dl1;
         s2 = l2 + (r.q[5].z - jd2 * di2); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
-        busy |= __ballot(absr(dl2) > r.q[7].w);
+        if (CHECK) busy |= __ballot(absr(dl2) > r.q[7].w);
       }
       if (d == 32) { R[26] = s0; R[27] = s1; R[28] = s2; }
       if (!in_lds) __threadfence_block();     // spilled records live in global memory: make lane 32's store visible to the wave
@@ -666,16 +687,9 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
         if (++c >= nc) break;
       }
     }
-    return !((busy >> 32) & 1ull);
+    return CHECK && !((busy >> 32) & 1ull);
   };
-  // the body is instantiated twice per trip: the multipliers are loop-carried, and with a single copy every new value has
-  // to be moved back into the register the loop header expects (~50 v_mov per iteration)
-  int it = 0;
-  while (it < P.iters) {
-    it++; if (iterate()) break;
-    if (it >= P.iters) break;
-    it++; if (iterate()) break;
-  }
+  const int it = pgs_iteration_loop(P.iters, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
   w.sync();
   if (d < nc) { const real* R = d < CL ? sh.b.crec[d] : ov.base + OVF_W_WORDS + (size_t)(d - CL) * CREC; sh.r_lam[3 * d] = R[26]; sh.r_lam[3 * d + 1] = R[27]; sh.r_lam[3 * d + 2] = R[28]; }
   if (d < ND) sh.u[d] += du;
