@@ -320,6 +320,11 @@ def main():
         c_end = float(st[:, cword].mean().item())
         mean_iters = float(st[:, iword].mean().item())
 
+    variants = None
+    if env is not None and not fly:
+        v = st[:, 114].long().clamp(0, 4)
+        cnt = torch.bincount(v, minlength=5).float() / v.numel()
+        variants = dict(zip(["dof_space", "row_space_no_arm_limits", "row_space_arm_limits", "row_space_exact", "row_space_rerun_exact"], [round(float(x), 4) for x in cnt]))
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed if not args.dry_run else None
@@ -346,6 +351,7 @@ def main():
                          "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel", "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches,
                          "alg_bytes_per_env_step": alg_bytes, "note": note},
             "sanity": {"state_finite": finite, "mean_contacts": 0.5 * (c_start + c_end), "mean_contacts_start": c_start, "mean_contacts_end": c_end,
+                       "pgs_variant_share": variants,
                        ("mean_episode_step" if fly else "mean_pgs_iters"): mean_iters},
         }
         if args.dry_run:
