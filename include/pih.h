@@ -50,8 +50,8 @@ enum {
   PIH_S_GRASP_ANGLE = 111, /* scripted mode: atan2 of the rotated grasp offset when the state machine entered state 2 (envs/peg_in_hole.py:72) */
   PIH_S_ATTACH_QZ = 113,   /* scripted mode: z component of the grasped link's quaternion when the state machine entered state 4 (the
                               reference passes it as targetOrn[2] into childFrameOrientation, envs/peg_in_hole.py:101) */
-  PIH_S_SOLVER = 114,      /* which PGS variant solved the last step: 0 DOF space, 1 / 2 row space (without / with the limit rows of joints
-                              0..6, unclamped motor rows), 3 row space exact, 4 row space re-run exact after a bound violation */
+  PIH_S_SOLVER = 114,      /* which PGS variant solved the last step: 0 DOF space, 1 / 2 row space without / with the limit rows of arm joints
+                              0..6, 4 row space re-run with all limit rows after an arm motor row clamped */
   PIH_S_INVALID = 112,     /* 1: the state became non-finite while auto_reset = 0; the env was re-initialised, marked done and stays frozen until pih_reset */
   PIH_S_CACHE_N = 128, PIH_S_CACHE_KEY = 129, PIH_S_CACHE_LAMBDA = 129 + 48
 };

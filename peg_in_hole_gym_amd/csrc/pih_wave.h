@@ -377,19 +377,16 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       const real tol = (real)1e-4 * ((real)1 + absr(vt) + absr(uj) + absr(vlo) + absr(vhi));
       skip7 = skip7 && (vt - vlo > tol) && (-vhi - vt > tol);
     }
+    // only with the huge impulse bound of the action-mode controller (1e5 dt): the scripted controller's 1200 dt does clamp
+    skip7 = skip7 && sh.mrec[0][3] >= (real)100;
     skip7 = __builtin_amdgcn_readfirstlane((int)skip7) != 0;
   }
   // ---- multipliers: wave-uniform values in VGPRs
   real lam_p[PIH_OBJ_NJ], lam_a[9], lam_lo[9], lam_hi[9];
   real v = 0;
   int it = 0;
-  // LIM7: keep the limit rows of arm joints 0..6; EXACT: clamp the motor rows to their impulse bounds in every update.  Without
-  // EXACT the 32 motor rows apply the UNCLAMPED update  d lambda = rhs - (J du) dinv  (readlane -> fma -> fmac: a dependent
-  // chain of three instead of five) and the bound is only watched (|lambda| > max impulse, in the checked iterations): the
-  // pipe's load-time motors (bound 1) carry impulses of ~5e-3 and the action-mode controller's bound is 1e5 dt, so a violation
-  // is not expected -- if one is seen, the solve is run again with EXACT.  Returns true if a bound was violated.
-  auto solve = [&](auto LIMTAG, auto EXACTTAG) __attribute__((always_inline)) -> bool {
-    constexpr bool FULL = decltype(LIMTAG)::value, EXACT = decltype(EXACTTAG)::value;
+  auto solve = [&](auto FULLTAG) __attribute__((always_inline)) -> bool {     // returns true if an arm motor row clamped
+    constexpr bool FULL = decltype(FULLTAG)::value;
 #pragma unroll
     for (int j = 0; j < PIH_OBJ_NJ; j++) lam_p[j] = 0;
 #pragma unroll
@@ -426,15 +423,9 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
           const real di = ca.x, rhs = ca.y, thr = ca.z, lim = ca.w;
           const real lor = cl.x, hir = cl.y, wjj = cl.z;
           real dj = rdlane(va, j);
-          real dl;
-          if (EXACT) {
-            real sum = lam_a[j] + (rhs - dj * di);
-            sum = med3_(sum, -lim, lim);
-            dl = sum - lam_a[j]; lam_a[j] = sum;
-          } else {
-            dl = rhs - dj * di; lam_a[j] += dl;
-            if (CHECK) clamped |= __ballot(absr(lam_a[j]) > lim);
-          }
+          real sum = lam_a[j] + (rhs - dj * di);
+          sum = med3_(sum, -lim, lim);
+          const real dl = sum - lam_a[j]; lam_a[j] = sum;
           if (CHECK) busy |= __ballot(absr(dl) > thr);
           if (FULL || j >= 7) {
             dj += dl * wjj;
@@ -447,21 +438,15 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
             if (CHECK) busy |= __ballot(absr(d3) > thr);
             va += A[j] * (dl + d2 - d3);
           } else {
-            if (EXACT && CHECK) clamped |= __ballot(absr(lam_a[j]) >= lim);     // (a multiplier at its bound stays there)
+            if (CHECK) clamped |= __ballot(absr(sum) >= lim);     // watched in the checked iterations (a multiplier at its bound stays there)
             va += A[j] * dl;
           }
         }
         const real di = cm.x, rhs = cm.y, thr = cm.z, lim = cm.w;
         const real dj = rdlane(vp, 9 + j);
-        real dl;
-        if (EXACT) {
-          real sum = lam_p[j] + (rhs - dj * di);
-          sum = med3_(sum, -lim, lim);
-          dl = sum - lam_p[j]; lam_p[j] = sum;
-        } else {
-          dl = rhs - dj * di; lam_p[j] += dl;
-          if (CHECK) clamped |= __ballot(absr(lam_p[j]) > lim);
-        }
+        real sum = lam_p[j] + (rhs - dj * di);
+        sum = med3_(sum, -lim, lim);
+        const real dl = sum - lam_p[j]; lam_p[j] = sum;
         if (CHECK) busy |= __ballot(absr(dl) > thr);
         vp += A[9 + j] * dl;
       }
@@ -500,16 +485,9 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
     it = pgs_iteration_loop(P.iters, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
     return clamped != 0;
   };
-  // action-mode impulse bounds (1e5 dt): unclamped motor rows, limit rows of joints 0..6 only when their targets ask for them; the
-  // scripted controller's bounds (1200 dt, 20 dt) do clamp: exact rows from the start
-  const bool fastok = __builtin_amdgcn_readfirstlane((int)(sh.mrec[0][3] >= (real)100)) != 0;
-  int variant = 3;
-  if (fastok) {
-    bool viol;
-    if (skip7) { viol = solve(std::false_type{}, std::false_type{}); variant = 1; }
-    else { viol = solve(std::true_type{}, std::false_type{}); variant = 2; }
-    if (viol) { solve(std::true_type{}, std::true_type{}); variant = 4; }
-  } else solve(std::true_type{}, std::true_type{});
+  int variant = 1;
+  if (!skip7) { solve(std::true_type{}); variant = 2; }
+  else if (solve(std::false_type{})) { solve(std::true_type{}); variant = 4; }
   if (lane == 0) sh.S[PIH_S_SOLVER] = (real)variant;
   w.sync();
   // ---- multipliers of the contacts back to r_lam; DOF velocities du = sum over rows of W_row * lambda_row (lane = DOF)
