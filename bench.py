@@ -68,15 +68,8 @@ def cpu_baseline(preroll=300, budget_s=25.0):
     fp32 all-cores row.  The sample is sized from a short probe so that the leg stays within ~budget_s."""
     import numpy as np
     from oracle import oracle as O
-    cores = usable_cores()
-    os.environ["OMP_NUM_THREADS"] = str(cores)
     outdir = tempfile.mkdtemp(prefix="pih_oracle_native_")
     p64, p32 = O.build_native(outdir)
-    try:      # libgomp is already in the process (torch): the environment variable alone would come too late
-        import ctypes
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
-    except Exception:  # noqa: BLE001
-        pass
     rng = np.random.default_rng(1234)
     rows = []
 
@@ -95,15 +88,18 @@ def cpu_baseline(preroll=300, budget_s=25.0):
                      "threads": threads, "mean_contacts": 0.5 * (c0 + c1)})
         return rows[-1]
 
-    # probe: how fast is this box?  (32 envs per core, 20 steps from reset, fp32)
-    probe_n = 32 * cores
-    o = O.Oracle(probe_n, lib_path=p32, auto_reset=1)
-    a = rng.uniform(-1, 1, (probe_n, 4))
-    t0 = time.perf_counter()
-    for _ in range(20):
+    # probe: how fast is this box, and with how many threads?  (20 steps from reset, fp32)
+    def probe(threads):
+        probe_n = 32 * threads
+        o = O.Oracle(probe_n, lib_path=p32, auto_reset=1)
+        a = rng.uniform(-1, 1, (probe_n, 4))
         o.step(a)
-    rate = probe_n * 20 / (time.perf_counter() - t0)          # free-fall steps: an upper bound of the steady-state rate
-    del o
+        t0 = time.perf_counter()
+        for _ in range(20):
+            o.step(a)
+        return probe_n * 20 / (time.perf_counter() - t0)      # free-fall steps: an upper bound of the steady-state rate
+
+    cores, rate = pick_threads(probe)
     # all-cores rows: envs so that (preroll + timed) fits the budget at ~rate/2 (contact steps cost ~2x free-fall ones)
     timed = 60
     n = int(max(4 * cores, min(4096, (0.35 * budget_s * rate / 2) / (preroll + timed))))
@@ -111,23 +107,15 @@ def cpu_baseline(preroll=300, budget_s=25.0):
     main = run(p32, n, preroll, timed, "fp32 -O3 -march=native, OpenMP over envs, %d threads" % cores, cores)
     run(p64, n, preroll, timed, "fp64 -O3 -march=native, OpenMP over envs, %d threads" % cores, cores)
     # the reference's own configuration shape: one env, one thread, 1000 random-action steps from reset
-    os.environ["OMP_NUM_THREADS"] = "1"
     try:
-        import ctypes
+        _omp_threads(1)
         for path in (p32, p64):
-            try:
-                ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
-            except Exception:  # noqa: BLE001
-                pass
             run(path, 1, 0, 1000, "%s -O3 -march=native, N = 1 env, 1 thread, 1000 steps from reset (BASELINE configs[0] shape)" % ("fp32" if path == p32 else "fp64"), 1)
     finally:
-        try:
-            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
-        except Exception:  # noqa: BLE001
-            pass
+        _omp_threads(cores)
     return {"value": main["value"], "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d steps after a %d-step pre-roll to contact steady state (mean contacts %.1f), fp32 build of the CPU "
-                      "restatement in oracle/ (NOT PyBullet), gcc -O3 -march=native, OpenMP over envs on all %d cores" % (n, timed, preroll, main["mean_contacts"], cores),
+                      "restatement in oracle/ (NOT PyBullet), gcc -O3 -march=native, OpenMP over envs, %d threads (the fastest of the thread counts probed)" % (n, timed, preroll, main["mean_contacts"], cores),
             "rows": rows}
 
 
@@ -135,15 +123,8 @@ def cpu_baseline_fly(preroll=300, budget_s=20.0):
     """The same for the random-fly task (oracle/pih_fly_oracle.c): fp32 / fp64 all cores, and N = 1 on one thread."""
     import numpy as np
     from oracle import oracle as O
-    cores = usable_cores()
-    os.environ["OMP_NUM_THREADS"] = str(cores)
     outdir = tempfile.mkdtemp(prefix="pih_oracle_native_")
     p64, p32 = O.build_native(outdir)
-    try:      # libgomp is already in the process (torch): the environment variable alone would come too late
-        import ctypes
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
-    except Exception:  # noqa: BLE001
-        pass
     rng = np.random.default_rng(1234)
     rows = []
 
@@ -159,30 +140,59 @@ def cpu_baseline_fly(preroll=300, budget_s=20.0):
         rows.append({"label": label, "value": n * steps / dt, "unit": "env-steps/s", "envs": n, "steps": steps, "preroll": pre, "threads": threads})
         return rows[-1]
 
-    probe = run(p32, 64 * cores, 0, 20, "probe", cores); rows.clear()
+    cores, rate = pick_threads(lambda k: run(p32, 64 * k, 0, 20, "probe", k)["value"]); rows.clear()
     timed = 100
-    n = int(max(8 * cores, min(16384, (0.4 * budget_s * probe["value"]) / (preroll + timed))))
+    n = int(max(8 * cores, min(16384, (0.4 * budget_s * rate) / (preroll + timed))))
     n -= n % cores
     main = run(p32, n, preroll, timed, "fp32 -O3 -march=native, OpenMP over envs, %d threads" % cores, cores)
     run(p64, n, preroll, timed, "fp64 -O3 -march=native, OpenMP over envs, %d threads" % cores, cores)
-    import ctypes
     try:
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+        _omp_threads(1)
         run(p32, 1, 0, 1000, "fp32 -O3 -march=native, N = 1 env, 1 thread, 1000 steps from reset", 1)
         run(p64, 1, 0, 1000, "fp64 -O3 -march=native, N = 1 env, 1 thread, 1000 steps from reset", 1)
     finally:
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+        _omp_threads(cores)
     return {"value": main["value"], "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d steps after a %d-step pre-roll, fp32 build of the CPU restatement in oracle/pih_fly_oracle.c (NOT PyBullet), "
-                      "gcc -O3 -march=native, OpenMP over envs on all %d cores" % (n, timed, preroll, cores), "rows": rows}
+                      "gcc -O3 -march=native, OpenMP over envs, %d threads (the fastest of the thread counts probed)" % (n, timed, preroll, cores), "rows": rows}
 
 
 def usable_cores():
-    """CPU cores this process may run on (the box's share), not the host's total"""
+    """CPU cores this process may run on: the affinity mask, cut to the cgroup CPU quota where one is set"""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:  # noqa: BLE001
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+def _omp_threads(k):
+    os.environ["OMP_NUM_THREADS"] = str(k)
+    try:      # libgomp is already in the process (torch): the environment variable alone would come too late
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(k))
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def pick_threads(probe):
+    """A GPU box's CPU share can be smaller than the affinity mask shows (16 cores of a 256-thread host, no visible quota):
+    time `probe(threads)` (env-steps/s of a short run) at the visible core count and at 16 / 32 / 64, keep the fastest."""
+    cores = usable_cores()
+    best, best_rate = cores, -1.0
+    for k in sorted({cores} | {c for c in (16, 32, 64) if c < cores}):
+        _omp_threads(k)
+        r = probe(k)
+        if r > best_rate * 1.05:
+            best, best_rate = k, r
+    _omp_threads(best)
+    return best, best_rate
 
 
 def _free_port():
