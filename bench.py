@@ -223,7 +223,7 @@ def main():
     ap.add_argument("--task", default="peg-in-hole", choices=["peg-in-hole", "random-fly"], help="random-fly = BASELINE configs[4]: UR5 + free-flying object, args=['Banana', 1/120.]")
     ap.add_argument("--mode", default="action", choices=["action", "scripted"], help="action = panda_execute per step (headline); scripted = the reference's grasp-and-insert state machine")
     ap.add_argument("--solver-path", type=int, default=0, help="1 = DOF-space PGS for every env (A/B against the default row-space path for <= 10 contacts)")
-    ap.add_argument("--schedule", type=int, default=1, help="dispatch order: 1 longest-job-first (default), 0 env order, 2 partner-aware (experimental)")
+    ap.add_argument("--schedule", type=int, default=1, help="dispatch order: 1 longest-job-first (default), 0 env order, 2 partner-aware (experimental); +4: no wave priority for heavy envs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (1-GPU box, gloo backend)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / collective / JSON plumbing only, no env and no GPU (CPU test of the N>1 path)")

@@ -97,7 +97,8 @@ typedef struct pih_config {
   int32_t enable_self_collision;
   int32_t debug;              /* 1: fill the debug buffer each step */
   int32_t schedule;           /* 1 (default): longest-job-first dispatch order from the previous step's contact counts; 0: block i = env i;
-                                 2: longest-job-first with the lightest envs as SIMD partners of the heaviest (experimental) */
+                                 2: longest-job-first with the lightest envs as SIMD partners of the heaviest (experimental);
+                                 +4: do not raise the issue priority of the wavefronts of contact-heavy envs (measurement switch) */
   int32_t enable_arm_collision; /* arm collision spheres (pih_model.h PIH_ARM_SPH_*): bit 0 vs the table plane, bit 1 vs the pipe (hand /
                                    flange / wrist spheres against the pipe's sample spheres); default 3 */
   int32_t task_id;            /* PIH_TASK_*: which task of TASK_LIST (envs/base_env.py:9-11) the handle simulates */

@@ -92,7 +92,7 @@ typedef real areal;
 
 struct Params {
   real dt, resid, erp, warm, margin, slop, ikdamp, ikres, dv;
-  int iters, ikiters, mode, maxsteps, autoreset, selfcol, armcol, debug, env0, pgsmode, attachball;
+  int iters, ikiters, mode, maxsteps, autoreset, selfcol, armcol, debug, env0, pgsmode, attachball, noprio;
   uint64_t seed;
 };
 

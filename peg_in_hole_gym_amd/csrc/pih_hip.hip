@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __rest
   __syncthreads();
   float o[5], r; unsigned char d;
   Ovf ov; ov.base = ovf + (size_t)env * OVF_WORDS;
-  w.dbg = dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr; w.dbgmode = P.debug;
+  w.dbg = dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr; w.dbgmode = P.debug; w.prio_on = !P.noprio;
   step_env(w, sh, P, ov, env, nullptr, o, &r, &d, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
   __syncthreads();
 #pragma unroll
@@ -327,7 +327,7 @@ static Params make_params(const pih_config* c) {
   P.dt = c->dt; P.resid = c->residual_threshold; P.erp = c->erp; P.warm = c->warmstart; P.margin = c->contact_margin;
   P.slop = c->linear_slop; P.ikdamp = c->ik_damping; P.ikres = c->ik_residual; P.dv = c->dv; P.iters = c->solver_iters;
   P.ikiters = c->ik_iters; P.mode = c->mode; P.maxsteps = c->max_episode_steps; P.autoreset = c->auto_reset;
-  P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball;
+  P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball; P.noprio = (c->schedule & 4) != 0;
   return P;
 }
 
@@ -394,8 +394,8 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
   }
   HIPCHK(h, hipMalloc(&h->ovf, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
   HIPCHK(h, hipMemset(h->ovf, 0, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
-  if (cfg->schedule) HIPCHK(h, hipMalloc(&h->order, (size_t)cfg->n_envs * sizeof(int)));
-  if (cfg->schedule == 2) { int cus = 0; HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device)); h->sched_k = 4 * cus; }
+  if (cfg->schedule & 3) HIPCHK(h, hipMalloc(&h->order, (size_t)cfg->n_envs * sizeof(int)));
+  if ((cfg->schedule & 3) == 2) { int cus = 0; HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device)); h->sched_k = 4 * cus; }
   hipLaunchKernelGGL(pih_init_offsets_kernel, dim3((cfg->n_envs + 63) / 64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
   hipLaunchKernelGGL(pih_reset_kernel, dim3(cfg->n_envs), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0);
   HIPCHK(h, hipGetLastError());

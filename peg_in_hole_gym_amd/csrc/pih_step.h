@@ -87,6 +87,7 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, const Ovf& ov, int env, 
     controller_rows(w, sh, P);
     w.phase(1);
     collide(w, sh, P);
+    w.priority(sh.nc);
     w.phase(2);
     w.par(ND, [&](int d) {
       real v;

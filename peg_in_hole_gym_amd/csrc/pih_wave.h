@@ -18,6 +18,16 @@ struct Wave {
   PIH_HD void phase_begin() { if (dbg && dbgmode == 2) t1 = __builtin_readcyclecounter(); }
   PIH_HD void phase(int k) { if (dbg && dbgmode == 2) { long long t = __builtin_readcyclecounter(); if (l == 0) dbg[900 + k] = (real)(t - t1); t1 = t; } }
   PIH_HD int lane() const { return l; }
+  // issue priority of this wavefront among the waves of its SIMD (s_setprio 0..3).  A launch of n envs ends when its heaviest
+  // env ends, and that env shares its SIMD with a light one for most of its life: the heavy wave goes first at every issue slot.
+  bool prio_on = true;
+  PIH_HD void priority(int contacts) {
+    if (!prio_on) return;
+    if (contacts > 20) __builtin_amdgcn_s_setprio(3);
+    else if (contacts > 14) __builtin_amdgcn_s_setprio(2);
+    else if (contacts > 10) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
   PIH_HD void sync() { __syncthreads(); }
   template <class F> PIH_HD void par(int n, F f) {
     __syncthreads();

@@ -30,6 +30,7 @@ struct Wave {
   void phase(int) {}
 #endif
   int lane() const { return 0; }
+  void priority(int) {}
   void sync() {}
   template <class F> void par(int n, F f) { for (int i = 0; i < n; i++) f(i); }
   // deterministic stream compaction: returns the slot of item i if valid (items are visited in index order)

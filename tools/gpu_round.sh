@@ -12,11 +12,12 @@ if [ "${2:-tests}" = "tests" ]; then
 fi
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_driver.json 2> $O/bench_${TAG}_driver.err || { echo "BENCH FAILED"; tail -20 $O/bench_${TAG}_driver.err; exit 1; }
 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_${TAG}.json 2> $O/bench_${TAG}.err || { echo "BENCH FAILED"; tail -20 $O/bench_${TAG}.err; exit 1; }
+timeout -k 10 300 python bench.py --no-cpu-baseline --schedule 5 > $O/bench_${TAG}_noprio.json 2> $O/bench_${TAG}_noprio.err || echo "NO-PRIORITY BENCH FAILED"
 timeout -k 10 300 python bench.py --no-cpu-baseline --solver-path 1 > $O/bench_${TAG}_dofspace.json 2> $O/bench_${TAG}_dofspace.err || echo "DOF-SPACE BENCH FAILED"
 timeout -k 10 300 python bench.py --task random-fly > $O/bench_${TAG}_fly.json 2> $O/bench_${TAG}_fly.err || { echo "FLY BENCH FAILED"; tail -20 $O/bench_${TAG}_fly.err; exit 1; }
 python - <<PY
 import json
-for f in ("bench_${TAG}_driver.json", "bench_${TAG}.json", "bench_${TAG}_dofspace.json", "bench_${TAG}_fly.json"):
+for f in ("bench_${TAG}_driver.json", "bench_${TAG}.json", "bench_${TAG}_noprio.json", "bench_${TAG}_dofspace.json", "bench_${TAG}_fly.json"):
     d = json.loads(open("$O/" + f).read().strip().splitlines()[-1])
     print(f, "%.3f M env-steps/s" % (d["value"] / 1e6), "kernel %.4f ms pre %.4f ms" % (d["roofline"]["kernel_avg_ms"], d["roofline"]["pre_kernel_avg_ms"]), "contacts", d["sanity"]["mean_contacts_start"], d["sanity"]["mean_contacts_end"], "cpu", d.get("cpu_baseline", {}).get("value"))
 PY
