@@ -8,17 +8,22 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for path in (0, 1):
     env = PihVecEnv(n, auto_reset=1, debug=2, solver_path=path, max_episode_steps=2227)
     gen = torch.Generator(device="cuda").manual_seed(1234)
-    tot = []; pgs = []; cnt = []
+    tot = []; pgs = []; cnt = []; smax = []; sarg = []; sph = []
     for t in range(460):
         env.step(torch.rand(n, 4, device="cuda", generator=gen) * 2 - 1)
         if t >= 400 and t % 5 == 0:
             d = env.debug()
             tot.append(d[:, 900:908].sum(1)); pgs.append(d[:, 905]); cnt.append(env.state()[:, 106])
+            i = int(tot[-1].argmax()); smax.append(float(tot[-1][i])); sarg.append(int(cnt[-1][i])); sph.append(d[i, 900:908].tolist())
     tot = torch.cat(tot); pgs = torch.cat(pgs); cnt = torch.cat(cnt)
     q = lambda x, p: float(torch.quantile(x.float(), p))
     print("solver_path %d: per-env cycles mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f | PGS mean %.0f | mean contacts %.2f | sum/2048 slots %.0f" % (
         path, tot.mean(), q(tot, .5), q(tot, .9), q(tot, .99), tot.max(), pgs.mean(), cnt.mean(), tot.sum() / len(tot) * n / 2048))
-    for lo, hi in ((0, 4), (5, 7), (8, 10), (11, 14), (15, 19), (20, 48)):
+    print("   heaviest env of a step (the launch cannot end before it does): mean %.0f cycles, min %.0f, max %.0f; its contacts: mean %.1f min %d max %d" % (
+        sum(smax) / len(smax), min(smax), max(smax), sum(sarg) / len(sarg), min(sarg), max(sarg)))
+    ph = torch.tensor(sph).mean(0).tolist()
+    print("   its phases: fk %.0f fsm %.0f collide %.0f aba %.0f rows %.0f pgs %.0f integrate %.0f fk2 %.0f" % tuple(ph))
+    for lo, hi in ((0, 4), (5, 7), (8, 10), (11, 14), (15, 19), (20, 24), (25, 32), (33, 48)):
         m = (cnt >= lo) & (cnt <= hi)
         if m.any():
             print("   contacts %2d..%2d: %5.1f %% of env-steps, total %.0f cycles, PGS %.0f" % (lo, hi, 100 * m.float().mean(), tot[m].mean(), pgs[m].mean()))
