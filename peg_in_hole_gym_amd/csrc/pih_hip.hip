@@ -24,12 +24,12 @@ using namespace pih;
 // of the block's first wavefront (controller_targets is strictly sequential per env; as wave-uniform code inside the
 // one-wave-per-env step kernel it ran at 1/64 lane utilisation).  The two parts touch disjoint state words.
 constexpr int PRE_THREADS = 256;
-// sched_k > 0 (config.schedule = 2): partner-aware variant of the order.  The first sched_k blocks (= number of SIMDs of the chip) are the
-// waves that get a SIMD to themselves at the start of the launch, the next sched_k become their co-resident partners: the heaviest
-// sched_k envs are followed by the LIGHTEST sched_k (so that the envs on the launch's critical path share their SIMD with short, light
-// waves), then the middle of the distribution in descending order.
+// sched_k > 0 (config.schedule = 2): "light seeds".  With n envs on m wave slots and n / m around 2, longest-job-first pairs the
+// heaviest env of the launch with the lightest one in the same slot -- the launch then ends a whole light env after the heaviest one.
+// Here the first wave of m blocks is the m - sched_k heaviest envs plus the sched_k LIGHTEST ones; the slots of those finish early, take
+// a second and a third light env, and the slots of the heaviest envs are never handed a second one.  sched_heads = m - sched_k.
 __global__ void __launch_bounds__(PRE_THREADS) pih_pre_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
-                                                               int* __restrict__ order, int n, int sched_k) {
+                                                               int* __restrict__ order, int n, int sched_heads, int sched_k) {
   const int t = threadIdx.x;
   if (blockIdx.x == 0) {
     if (!order) return;
@@ -48,10 +48,7 @@ __global__ void __launch_bounds__(PRE_THREADS) pih_pre_kernel(Params P, float* _
       int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
       k = k < 0 ? 0 : (k > 63 ? 63 : k);
       int r = atomicAdd(&base[63 - k], 1);
-      if (sched_k > 0 && n > sched_k) {
-        const int k2 = n - sched_k < sched_k ? n - sched_k : sched_k;
-        if (r >= sched_k) r = r >= n - k2 ? sched_k + (n - 1 - r) : r + k2;
-      }
+      if (sched_k > 0 && n > sched_heads + sched_k && r >= sched_heads) r = r >= n - sched_k ? sched_heads + (n - 1 - r) : r + sched_k;
       order[r] = e;
     }
     return;
@@ -286,7 +283,7 @@ struct pih_handle {
   pih_config cfg;
   Params P;
   int device = 0;
-  int sched_k = 0;          // config.schedule = 2: number of SIMDs of the device (partner-aware dispatch order)
+  int sched_k = 0, sched_heads = 0;   // config.schedule = 2: light seeds in the first wave of blocks (see pih_pre_kernel)
   bool fly = false;         // PIH_TASK_RANDOM_FLY: structure-of-arrays state, one env per lane
   int words = PIH_STATE_WORDS;
   float* state = nullptr;
@@ -395,7 +392,13 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
   HIPCHK(h, hipMalloc(&h->ovf, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
   HIPCHK(h, hipMemset(h->ovf, 0, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
   if (cfg->schedule & 3) HIPCHK(h, hipMalloc(&h->order, (size_t)cfg->n_envs * sizeof(int)));
-  if ((cfg->schedule & 3) == 2) { int cus = 0; HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device)); h->sched_k = 4 * cus; }
+  if ((cfg->schedule & 3) == 2) {
+    int cus = 0; HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int slots = 8 * cus;                    // two 256-VGPR wavefronts on each of the 4 SIMDs of a CU
+    h->sched_k = slots / 16;
+    if (const char* e = getenv("PIH_SCHED_K")) h->sched_k = atoi(e);      // measurement override
+    h->sched_heads = slots - h->sched_k;
+  }
   hipLaunchKernelGGL(pih_init_offsets_kernel, dim3((cfg->n_envs + 63) / 64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
   hipLaunchKernelGGL(pih_reset_kernel, dim3(cfg->n_envs), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0);
   HIPCHK(h, hipGetLastError());
@@ -456,7 +459,7 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
     HIPCHK(h, hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(pih_pre_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs, h->sched_k);
+  hipLaunchKernelGGL(pih_pre_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs, h->sched_heads, h->sched_k);
   if (t) HIPCHK(h, hipEventRecord(t->b, s));
   hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, obs, reward, done, h->dbg, h->ovf, h->order);
   if (t) HIPCHK(h, hipEventRecord(t->c, s));

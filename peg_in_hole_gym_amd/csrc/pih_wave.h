@@ -15,8 +15,15 @@ struct Wave {
   static constexpr bool controller_inline = false;          // the controller runs in pih_pre_kernel, one env per lane
   real* dbg = nullptr; int dbgmode = 0; long long t0 = 0, t1 = 0;   // diagnostic shader-clock stamps (config.debug == 2; never read by the kernel)
   PIH_HD void stamp(int k) { if (dbg && dbgmode == 2) { long long t = __builtin_readcyclecounter(); if (l == 0) dbg[900 + k] = (real)(t - t0); t0 = t; } }   // sub-phases
-  PIH_HD void phase_begin() { if (dbg && dbgmode == 2) t1 = __builtin_readcyclecounter(); }
-  PIH_HD void phase(int k) { if (dbg && dbgmode == 2) { long long t = __builtin_readcyclecounter(); if (l == 0) dbg[900 + k] = (real)(t - t1); t1 = t; } }
+  // debug words 940..949: start / end of the env's wave on the chip-wide 100 MHz clock (s_memrealtime; three 16-bit pieces each), HW_ID, XCC_ID: the
+  // launch's dispatch timeline (tools/sched_trace.py)
+  PIH_HD void trace(int at, long long t) {
+    if (l != 0) return;
+    dbg[at] = (real)(t & 0xFFFF); dbg[at + 1] = (real)((t >> 16) & 0xFFFF); dbg[at + 2] = (real)((t >> 32) & 0xFFFF);
+    if (at == 940) { dbg[946] = (real)(__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xFFFF); dbg[947] = (real)__builtin_amdgcn_s_getreg((3 << 11) | 20); }
+  }
+  PIH_HD void phase_begin() { if (dbg && dbgmode == 2) { t1 = __builtin_readcyclecounter(); trace(940, (long long)__builtin_amdgcn_s_memrealtime()); } }
+  PIH_HD void phase(int k) { if (dbg && dbgmode == 2) { long long t = __builtin_readcyclecounter(); if (l == 0) dbg[900 + k] = (real)(t - t1); t1 = t; if (k == 7) trace(943, (long long)__builtin_amdgcn_s_memrealtime()); } }
   PIH_HD int lane() const { return l; }
   // issue priority of this wavefront among the waves of its SIMD (s_setprio 0..3).  A launch of n envs ends when its heaviest
   // env ends, and that env shares its SIMD with a light one for most of its life: the heavy wave goes first at every issue slot.
@@ -356,19 +363,34 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       }
     } else { A[NMOT + 3 * c] = 0; A[NMOT + 3 * c + 1] = 0; A[NMOT + 3 * c + 2] = 0; }
   }
-  // ---- pack the per-contact solver constants (16 words, read as 4 x b128 broadcasts per iteration) over the first half of the
-  // contact record, whose geometry is no longer needed:
-  //   0 rhs_n  1 rhs_t1  2 rhs_t2  3 G[t1][n] | 4 G[t2][n]  5 G[t2][t1]  6 mu  7 lo_n | 8 hi_floor  9 dinv_n  10 dinv_t1  11 dinv_t2 |
-  //   12 thr_n  13 thr_t1  14 thr_t2  15 - | 16 lambda_n  17 lambda_t1  18 lambda_t2 (running multipliers, rewritten by lane 0)
+  // ---- per-lane row constants.  The solve runs on z = lambda + rhs - dinv (J du) of the lane's own row ("the multiplier the row
+  // would take if it were not clamped"): a row update is then  lambda' = clamp(z),  d = lambda' - lambda,  and every lane's z moves
+  // by  -dinv A[i] d  -- except the updated row's own z, which stays where it is (dinv A[i][i] = 1).  With Bn[i] = [lane == i] -
+  // dinv A[i] (in the registers that held A) the whole update of row i is
+  //     clamp (v_med3) -> subtract -> v_readlane -> one FMA on z
+  // three dependent VALU operations and a readlane instead of readlane -> FMA -> clamp -> subtract -> FMA, no row constant is
+  // fetched inside the loop (bounds, threshold and multiplier of a row live in its lane), and the running multipliers of the pipe
+  // motors and the contacts need no wave-uniform registers.  The arm joints keep their uniform chain (motor, lower, upper limit
+  // share one lane): their lanes hold z = -dinv (J du).
   w.sync();
-  if (lane < nc) {
-    real* R = sh.b.crec[lane];
-    const real r0 = R[20], r1 = R[21], r2 = R[22], g10 = R[23], g20 = R[24], g21 = R[25], mu = R[5], lon = R[3], hif = R[4];
-    const real d0 = R[11], d1 = R[15], d2 = R[19], t0 = R[29], t1 = R[30], t2 = R[31];
-    R[0] = r0; R[1] = r1; R[2] = r2; R[3] = g10; R[4] = g20; R[5] = g21; R[6] = mu; R[7] = lon;
-    R[8] = hif; R[9] = d0; R[10] = d1; R[11] = d2; R[12] = t0; R[13] = t1; R[14] = t2; R[15] = 0;
+  real di = 0, rhs = 0, thr = PIH_BIG, lbv = 0, ubv = 0, cmu = 0, cfl = 0, lam0 = 0;
+  if (lane < 9) di = sh.mrec[lane][0];
+  else if (lane < NMOT) { di = sh.mrec[lane][0]; rhs = sh.mrec[lane][1]; thr = sh.mrec[lane][2]; ubv = sh.mrec[lane][3]; lbv = -ubv; }
+  else {
+    const int row = lane - NMOT, c = row / 3, k = row - 3 * c;
+    if (c < nc) {
+      const real* R = sh.b.crec[c];
+      di = R[11 + 4 * k]; rhs = R[20 + k]; thr = R[29 + k]; cmu = R[5]; cfl = R[4];
+      if (k == 0) { lbv = R[3]; ubv = PIH_BIG; lam0 = sh.r_lam[3 * c]; }      // friction rows: bounds set per iteration from the normal multiplier
+    }
   }
-  w.sync();
+  // (sqrt(resid) * dinv of a contact row sits in words 29..31 of its record, the multipliers go back to sh.r_lam)
+#pragma unroll
+  for (int i = 0; i < FR; i++) { A[i] = (lane == i && lane >= 9 ? (real)1 : (real)0) - di * A[i]; }
+  real* const Bn = A;
+  unsigned long long angmask = 0;          // contacts whose friction rows are always solved (mu < 0: the attach weld's rows)
+#pragma unroll
+  for (int c = 0; c < MERGED_CONTACTS; c++) if (c < nc && sh.b.crec[c][5] < 0) angmask |= 1ull << c;
   // ---- the limit rows of arm joints 0..6 are exact no-ops for the whole solve when (a) the joint's motor row is never clamped --
   // an unclamped velocity motor sets the joint's velocity change to (target - current) whatever it was, because J W dinv = 1 -- and
   // (b) that target velocity violates neither limit speed: then  rhs_limit - (J du) dinv = (v_limit - v_target) dinv < 0  every time
@@ -391,104 +413,104 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
     skip7 = skip7 && sh.mrec[0][3] >= (real)100;
     skip7 = __builtin_amdgcn_readfirstlane((int)skip7) != 0;
   }
-  // ---- multipliers: wave-uniform values in VGPRs
-  real lam_p[PIH_OBJ_NJ], lam_a[9], lam_lo[9], lam_hi[9];
-  real v = 0;
+  if (lane < 9) sh.lrec[lane][3] = sh.lrec[lane][2] * sh.mrec[lane][0];          // (J W) dinv of the arm joint (1 up to rounding)
+  w.sync();
+  // ---- multipliers: arm rows wave-uniform in VGPRs, every other row in its own lane
+  real lam_a[9], lam_lo[9], lam_hi[9];
+  real lam = 0, z = 0;
   int it = 0;
+  // commit one lane of a per-lane register: x[g] = y[g] (the lane mask is a compile-time constant in an SGPR pair)
+  auto commit = [&](real& x, real y, int g) __attribute__((always_inline)) {
+    const unsigned long long m = 1ull << g;
+    __asm__("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(y), "s"(m));
+  };
   auto solve = [&](auto FULLTAG) __attribute__((always_inline)) -> bool {     // returns true if an arm motor row clamped
     constexpr bool FULL = decltype(FULLTAG)::value;
 #pragma unroll
-    for (int j = 0; j < PIH_OBJ_NJ; j++) lam_p[j] = 0;
-#pragma unroll
     for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
-    v = 0;
+    lam = lam0;
+    {
+      real v = 0;                          // warm start: J du of the cached normal multipliers, z = lambda + rhs - dinv (J du)
 #pragma unroll
-    for (int c = 0; c < MERGED_CONTACTS; c++)
-      if (c < nc) { v += A[NMOT + 3 * c] * sh.r_lam[3 * c]; if (lane == 0) { real* R = sh.b.crec[c]; R[16] = sh.r_lam[3 * c]; R[17] = 0; R[18] = 0; } }   // warm start
+      for (int c = 0; c < MERGED_CONTACTS; c++)
+        if (c < nc) v += Bn[NMOT + 3 * c] * sh.r_lam[3 * c];
+      z = rhs + v;                         // (Bn = [own] - dinv A: the sum is  [own normal row] lam0 - dinv (J du))
+    }
     unsigned long long clamped = 0;
     auto iterate = [&](auto CHECKTAG) __attribute__((always_inline)) -> bool {
-      constexpr bool CHECK = decltype(CHECKTAG)::value;     // evaluate the early-exit test in this iteration? (see pgs_iteration_checks)
+      constexpr bool CHECK = decltype(CHECKTAG)::value;     // evaluate the early-exit test in this iteration? (see pgs_iteration_loop)
       unsigned long long busy = 0;
-      __asm__ volatile("" ::: "memory");      // keep the row constants in LDS (see pgs(): LICM would hoist and spill them)
+      __asm__ volatile("" ::: "memory");      // keep the arm row constants in LDS (see pgs(): LICM would hoist and spill them)
       constexpr int PF = 4;
-      real4 pm[PF], pa4[PF], pl4[PF];
+      real4 pa4[PF], pl4[PF];
 #pragma unroll
-      for (int k = 0; k < PF; k++) { pm[k] = *reinterpret_cast<const real4*>(sh.mrec[9 + k]); pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
-      // the first contact's constants are fetched before the motor chain, each further one while its predecessor is being solved
-      struct CQ { real4 q0, q1, q2, q3, q4; };
-      auto fetchc = [&](int c) __attribute__((always_inline)) -> CQ {
-        const real4* R = reinterpret_cast<const real4*>(sh.b.crec[c]);
-        CQ r; r.q0 = R[0]; r.q1 = R[1]; r.q2 = R[2]; r.q3 = R[3]; r.q4 = R[4]; return r;
-      };
-      CQ cq = fetchc(0);
+      for (int k = 0; k < PF; k++) { pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
       // the arm rows and the pipe motor rows do not see each other (A[arm row][pipe motor row] = 0): two accumulators, two chains
-      real va = v, vp = v;
+      real za = z, zp = z;
 #pragma unroll
       for (int j = 0; j < PIH_OBJ_NJ; j++) {
-        const real4 cm = pm[j % PF];
-        if (j + PF < PIH_OBJ_NJ) pm[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[9 + j + PF]);
-        if (j < 9) {   // arm joint block: motor, lower limit, upper limit
+        if (j < 9) {   // arm joint block: motor, lower limit, upper limit; y = dinv (J du) of the joint
           const real4 ca = pa4[j % PF], cl = pl4[j % PF];
           if (j + PF < 9) { pa4[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[j + PF]); pl4[j % PF] = *reinterpret_cast<const real4*>(sh.lrec[j + PF]); }
-          const real di = ca.x, rhs = ca.y, thr = ca.z, lim = ca.w;
-          const real lor = cl.x, hir = cl.y, wjj = cl.z;
-          real dj = rdlane(va, j);
-          real sum = lam_a[j] + (rhs - dj * di);
+          const real rh = ca.y, th = ca.z, lim = ca.w;
+          const real lor = cl.x, hir = cl.y, wd = cl.w;
+          real y = -rdlane(za, j);
+          real sum = lam_a[j] + (rh - y);
           sum = med3_(sum, -lim, lim);
           const real dl = sum - lam_a[j]; lam_a[j] = sum;
-          if (CHECK) busy |= __ballot(absr(dl) > thr);
+          if (CHECK) busy |= __ballot(absr(dl) > th);
           if (FULL || j >= 7) {
-            dj += dl * wjj;
-            real s2 = lam_lo[j] + (lor - dj * di); s2 = max_(s2, (real)0);
+            y += dl * wd;
+            real s2 = lam_lo[j] + (lor - y); s2 = max_(s2, (real)0);
             const real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
-            if (CHECK) busy |= __ballot(absr(d2) > thr);
-            dj += d2 * wjj;
-            real s3 = lam_hi[j] + (hir + dj * di); s3 = max_(s3, (real)0);
+            if (CHECK) busy |= __ballot(absr(d2) > th);
+            y += d2 * wd;
+            real s3 = lam_hi[j] + (hir + y); s3 = max_(s3, (real)0);
             const real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
-            if (CHECK) busy |= __ballot(absr(d3) > thr);
-            va += A[j] * (dl + d2 - d3);
+            if (CHECK) busy |= __ballot(absr(d3) > th);
+            za += Bn[j] * (dl + d2 - d3);
           } else {
             if (CHECK) clamped |= __ballot(absr(sum) >= lim);     // watched in the checked iterations (a multiplier at its bound stays there)
-            va += A[j] * dl;
+            za += Bn[j] * dl;
           }
         }
-        const real di = cm.x, rhs = cm.y, thr = cm.z, lim = cm.w;
-        const real dj = rdlane(vp, 9 + j);
-        real sum = lam_p[j] + (rhs - dj * di);
-        sum = med3_(sum, -lim, lim);
-        const real dl = sum - lam_p[j]; lam_p[j] = sum;
-        if (CHECK) busy |= __ballot(absr(dl) > thr);
-        vp += A[9 + j] * dl;
+        // pipe motor row 9 + j: every lane clamps its own z, the row's lane supplies the step
+        const int g = 9 + j;
+        const real cand = med3_(zp, lbv, ubv);
+        const real dlv = cand - lam;
+        const real sdl = rdlane(dlv, g);
+        if (CHECK) busy |= __ballot(absr(dlv) > thr) & (1ull << g);
+        commit(lam, cand, g);
+        zp += Bn[g] * sdl;
       }
-      v = (va + vp) - v;
-      // contacts: exact 3x3 Gauss-Seidel block in row space
-      //   q0 = rhs n,t1,t2, G[t1][n] | q1 = G[t2][n], G[t2][t1], mu, lo_n | q2 = hi_floor, dinv n,t1,t2 | q3 = thr n,t1,t2 | q4 = lambda n,t1,t2
+      z = (za + zp) - z;
+      // contacts: normal, dir1, dir2 -- the friction bounds follow the normal multiplier; Bullet leaves the friction rows of an
+      // unloaded contact alone: their bounds collapse onto the current multiplier (step 0) instead of a branch
 #pragma unroll
       for (int c = 0; c < MERGED_CONTACTS; c++) {
-        if (c >= nc) break;                              // single exit: no per-contact merge of the 20-register prefetch buffer
-        const real4 q0 = cq.q0, q1 = cq.q1, q2 = cq.q2, q3 = cq.q3, q4 = cq.q4;
-        cq = fetchc(c + 1 < MERGED_CONTACTS ? c + 1 : c);   // unconditional: beyond the last contact the record is loaded and never used
-        real* Rw = sh.b.crec[c];
+        if (c >= nc) break;
         const int g0 = NMOT + 3 * c;
-        const real vn = rdlane(v, g0);
-        real vt1 = rdlane(v, g0 + 1), vt2 = rdlane(v, g0 + 2);
-        const real l0 = q4.x, l1 = q4.y, l2 = q4.z;
-        real s0 = l0 + (q0.x - vn * q2.y);
-        s0 = max_(s0, q1.w);
-        const real dl0 = s0 - l0;
-        if (CHECK) busy |= __ballot(absr(dl0) > q3.x);
-        real dl1 = 0, dl2 = 0, s1 = l1, s2 = l2;
-        if (rdlane(s0, 0) > 0 || rdlane(q1.z, 0) < 0) {   // wave-uniform (Bullet skips the friction rows of an unloaded contact)
-          const real hi = max_(q1.z * s0, q2.x);
-          vt1 += q0.w * dl0;
-          s1 = l1 + (q0.y - vt1 * q2.z); s1 = med3_(s1, -hi, hi); dl1 = s1 - l1;
-          if (CHECK) busy |= __ballot(absr(dl1) > q3.y);
-          vt2 += q1.x * dl0 + q1.y * dl1;
-          s2 = l2 + (q0.z - vt2 * q2.w); s2 = med3_(s2, -hi, hi); dl2 = s2 - l2;
-          if (CHECK) busy |= __ballot(absr(dl2) > q3.z);
-        }
-        if (lane == 0) { Rw[16] = s0; Rw[17] = s1; Rw[18] = s2; }
-        v += A[g0] * dl0 + A[g0 + 1] * dl1 + A[g0 + 2] * dl2;
+        const real cn = med3_(z, lbv, ubv);
+        const real dn = cn - lam;
+        const real s0 = rdlane(cn, g0), sdn = rdlane(dn, g0);
+        if (CHECK) busy |= __ballot(absr(dn) > thr) & (1ull << g0);
+        commit(lam, cn, g0);
+        z += Bn[g0] * sdn;
+        const bool loaded = s0 > 0 || ((angmask >> c) & 1ull);
+        const real hi = max_(cmu * s0, cfl);
+        const real fl = loaded ? -hi : lam, fh = loaded ? hi : lam;
+        const real c1 = med3_(z, fl, fh);
+        const real d1 = c1 - lam;
+        const real sd1 = rdlane(d1, g0 + 1);
+        if (CHECK) busy |= __ballot(absr(d1) > thr) & (1ull << (g0 + 1));
+        commit(lam, c1, g0 + 1);
+        z += Bn[g0 + 1] * sd1;
+        const real c2 = med3_(z, fl, fh);
+        const real d2 = c2 - lam;
+        const real sd2 = rdlane(d2, g0 + 2);
+        if (CHECK) busy |= __ballot(absr(d2) > thr) & (1ull << (g0 + 2));
+        commit(lam, c2, g0 + 2);
+        z += Bn[g0 + 2] * sd2;
       }
       return CHECK && busy == 0;
     };
@@ -499,9 +521,9 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
   if (!skip7) { solve(std::true_type{}); variant = 2; }
   else if (solve(std::false_type{})) { solve(std::true_type{}); variant = 4; }
   if (lane == 0) sh.S[PIH_S_SOLVER] = (real)variant;
-  w.sync();
-  // ---- multipliers of the contacts back to r_lam; DOF velocities du = sum over rows of W_row * lambda_row (lane = DOF)
-  if (lane < nc) { const real* R = sh.b.crec[lane]; sh.r_lam[3 * lane] = R[16]; sh.r_lam[3 * lane + 1] = R[17]; sh.r_lam[3 * lane + 2] = R[18]; }
+  // multipliers back to LDS: contacts -> r_lam, pipe motors -> word 1 of their (now unused) constant record
+  if (lane >= NMOT && lane < NMOT + 3 * nc) sh.r_lam[lane - NMOT] = lam;
+  if (lane >= 9 && lane < NMOT) sh.mrec[lane][1] = lam;
   w.sync();
   {
     const int d = lane, dw = d < ND ? d : ND;
@@ -511,7 +533,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       for (int j = 0; j < 9; j++) du += wma_row(sh, j)[d] * (lam_a[j] + lam_lo[j] - lam_hi[j]);
     } else if (d < ND) {
 #pragma unroll
-      for (int j = 0; j < PIH_OBJ_NJ; j++) du += wmp_row(sh, j)[d - 9] * lam_p[j];
+      for (int j = 0; j < PIH_OBJ_NJ; j++) du += wmp_row(sh, j)[d - 9] * sh.mrec[9 + j][1];
     }
 #pragma unroll
     for (int c = 0; c < MERGED_CONTACTS; c++)
