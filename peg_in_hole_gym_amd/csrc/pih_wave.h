@@ -57,6 +57,12 @@ struct Wave {
   }
 };
 // ------------------------------------------------------------------------------------------------ cross-lane helpers
+// x[g] = y[g] for ONE lane g known at compile time.  The lane mask is made on the spot by the scalar unit (s_lshl_b64 of inline
+// constants): as a 64-bit constant operand it would be hoisted out of the solver loop, one SGPR pair per row, and spilled.
+PIH_HD void commit_lane(real& x, real y, int g) {
+  unsigned long long m;
+  __asm__ volatile("s_lshl_b64 %1, 1, %3\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(x), "=&s"(m) : "v"(y), "n"(g) : "scc");   // s_lshl_b64 writes SCC
+}
 PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane must be wave-uniform): v_readlane_b32
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -420,10 +426,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
   real lam = 0, z = 0;
   int it = 0;
   // commit one lane of a per-lane register: x[g] = y[g] (the lane mask is a compile-time constant in an SGPR pair)
-  auto commit = [&](real& x, real y, int g) __attribute__((always_inline)) {
-    const unsigned long long m = 1ull << g;
-    __asm__("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(y), "s"(m));
-  };
+  auto commit = [&](real& x, real y, int g) __attribute__((always_inline)) { commit_lane(x, y, g); };
   auto solve = [&](auto FULLTAG) __attribute__((always_inline)) -> bool {     // returns true if an arm motor row clamped
     constexpr bool FULL = decltype(FULLTAG)::value;
 #pragma unroll
@@ -544,6 +547,258 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
   return it;
 }
 
+// ---- the same solver with TWO rows per lane, for envs with 11 .. HC contacts (128 rows; a fifth of the env-steps of the benchmark
+// workload and every one of its slowest: their DOF-space blocks were what a launch of 4096 envs waited for).  Row g lives in lane
+// g % 64 of register set g / 64.  The 128 x 128 matrix no longer fits the register file: the columns of the motor rows and of the
+// first 10 contacts (KREG = 62) stay in registers, the others are written once per step to the env's scratch in global memory
+// ([column][lane][2], 512 B per column, L2-resident) and streamed through a ring of D prefetched columns in every iteration --
+// the addresses do not depend on the solve, so the loads are issued a ring ahead and never sit on the row chain.
+// Motor columns come from the symmetry of the Delassus matrix, A[r][motor m] = W_r[dof(m)], without a dot product.
+PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW& mw) {
+  const int nc = __builtin_amdgcn_readfirstlane(sh.nc);
+  w.sync();
+  const int lane = w.lane();
+  constexpr int D = 12;                                    // ring depth (columns in flight)
+  real* const Bg = ov.base + OVF_B_OFF + 2 * lane;         // this lane's slot of streamed column s: Bg[s * 128 .. +1]
+  // one streamed column (both rows of the lane) = one 8-byte buffer load: lane * 8 in the vector offset, the column in the SCALAR
+  // offset (no 64-bit address arithmetic in vector registers).  The column index is clamped and made opaque at every use: otherwise
+  // the loop-invariant indices / addresses of all 84 columns are hoisted out of the iteration loop and spilled.
+  struct F2 { real x, y; };
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(ov.base + OVF_B_OFF), 0, OVF_B_WORDS * 4, 0x00020000);
+  int nsm1 = NMOT + 3 * nc - KREG - 1;                    // last streamed column (>= 0: this solver runs for nc > 10)
+  auto ldcol = [&](int sidx, int l8) __attribute__((always_inline)) -> F2 {
+    int hi = nsm1;
+    __asm__ volatile("" : "+s"(hi));
+    sidx = sidx < hi ? sidx : hi;
+    // (two adjacent b32 loads, which the backend merges into one buffer_load_dwordx2: this toolchain's raw_buffer_load_b64 /
+    //  _b128 builtins are lowered to a single dword replicated into every element)
+    F2 r; r.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, l8, sidx * 512, 0));
+    r.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, l8 + 4, sidx * 512, 0)); return r;
+  };
+  // ---- rows of this lane: r0 = lane (motor row, or contact row lane - 32), r1 = 64 + lane (contact row 32 + lane)
+  struct RowC { real di, rhs, thr, lb, ub, mu, fl, lam0; };
+  auto rowconst = [&](int g) __attribute__((always_inline)) -> RowC {
+    RowC r; r.di = 0; r.rhs = 0; r.thr = PIH_BIG; r.lb = 0; r.ub = 0; r.mu = 0; r.fl = 0; r.lam0 = 0;
+    if (g < 9) r.di = sh.mrec[g][0];
+    else if (g < NMOT) { r.di = sh.mrec[g][0]; r.rhs = sh.mrec[g][1]; r.thr = sh.mrec[g][2]; r.ub = sh.mrec[g][3]; r.lb = -r.ub; }
+    else {
+      const int row = g - NMOT, c = row / 3, k = row - 3 * c;
+      if (c < nc) {
+        const real* R = c < CL ? sh.b.crec[c] : ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC;
+        r.di = R[11 + 4 * k]; r.rhs = R[20 + k]; r.thr = R[29 + k]; r.mu = R[5]; r.fl = R[4];
+        if (k == 0) { r.lb = R[3]; r.ub = PIH_BIG; r.lam0 = sh.r_lam[3 * c]; }
+      }
+    }
+    return r;
+  };
+  const RowC c0 = rowconst(lane), c1 = rowconst(64 + lane);
+  // ---- columns.  Bn[i] = [own row] - dinv A[i]
+  real B0[KREG], B1[KREG];
+  // motor columns by symmetry: A[r][m] = W_r[dof(m)].  Contact rows read their own response row; motor rows take the (lane = DOF)
+  // registers of the motor rows: arm lane r holds W_m[r] itself, pipe lane r finds W_m[dof(r)] six lanes up
+  {
+    const int row0 = lane - NMOT, row1 = 32 + lane;                 // contact-row index of r0 (if >= 0) and r1
+    const real* w0 = row0 >= 0 && row0 < 3 * nc ? wp_row(sh, ov, row0) : nullptr;
+    const real* w1 = row1 < 3 * nc ? wp_row(sh, ov, row1) : nullptr;
+#pragma unroll
+    for (int m = 0; m < NMOT; m++) {
+      const int dm = m < 9 ? m : 15 + (m - 9);
+      real a0;
+      if (m < 9) a0 = lane < 9 ? mw.w[m] : (real)0;
+      else {
+        const real up = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * ((lane + 6) & 63), __builtin_bit_cast(int, mw.w[m - 9])));
+        a0 = (lane >= 9 && lane < NMOT) ? up : (real)0;
+      }
+      if (w0) a0 = w0[dm];
+      const real a1 = w1 ? w1[dm] : (real)0;
+      B0[m] = ((lane == m && m >= 9) ? (real)1 : (real)0) - c0.di * a0;
+      B1[m] = -c1.di * a1;
+      __asm__ volatile("" : "+v"(B0[m]), "+v"(B1[m]) :: "memory");
+    }
+  }
+  // the motor rows' registers are not needed again before the very end: park them in the env's scratch
+  real* const Mg = ov.base + OVF_MW_OFF + lane;
+#pragma unroll
+  for (int j = 0; j < PIH_OBJ_NJ; j++) Mg[j * 64] = mw.w[j];
+  // ---- Jacobian rows (registers) of both rows of the lane
+  real J0[ND], J1[ND];
+  {
+    auto geom = [&](int g, int& la, int& lb, V3& p, V3& dir, bool& ang, bool& live) __attribute__((always_inline)) {
+      la = -1; lb = -1; p = mk(0, 0, 0); dir = mk(0, 0, 0); ang = false; live = false;
+      if (g < NMOT) return;
+      const int row = g - NMOT, c = row / 3, k = row - 3 * c;
+      if (c >= nc) return;
+      live = true; la = sh.c_la[c]; lb = sh.c_lb[c];
+      const real* R = c < CL ? sh.b.crec[c] : ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC;
+      p = ld3(R); dir = ld3(R + 8 + 4 * k); ang = R[6] != 0;
+    };
+    int la0, lb0, la1, lb1; V3 p0, d0, p1, d1; bool a0, a1, l0, l1;
+    geom(lane, la0, lb0, p0, d0, a0, l0); geom(64 + lane, la1, lb1, p1, d1, a1, l1);
+    const int md = lane < 9 ? lane : 15 + (lane - 9);
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+      const DofGeom g = dof_geom(sh, d);
+      J0[d] = lane < NMOT ? (d == md ? (real)1 : (real)0) : (l0 ? jac_entry(g, la0, lb0, p0, d0, a0) : (real)0);
+      J1[d] = l1 ? jac_entry(g, la1, lb1, p1, d1, a1) : (real)0;
+      __asm__ volatile("" : "+v"(J0[d]), "+v"(J1[d]) :: "memory");
+    }
+  }
+  // contact columns: J . W_i, the response row W_i broadcast from LDS (contacts < CL) or from the env's scratch
+  w.sync();
+#pragma unroll 1
+  for (int cb = 0; cb < HC; cb++) {                          // (rolled: the register-resident columns are handled by the switch below)
+    if (cb >= nc) break;
+    for (int k = 0; k < 3; k++) {
+      const int i = NMOT + 3 * cb + k;
+      const real* wr = wp_row(sh, ov, 3 * cb + k);
+      real a0 = 0, a1 = 0;
+#pragma unroll
+      for (int d = 0; d < ND; d++) { const real wv = wr[d]; a0 += J0[d] * wv; a1 += J1[d] * wv; }
+      const real b0 = (lane == i ? (real)1 : (real)0) - c0.di * a0, b1 = (64 + lane == i ? (real)1 : (real)0) - c1.di * a1;
+      if (i >= KREG) { Bg[(size_t)(i - KREG) * 128] = b0; Bg[(size_t)(i - KREG) * 128 + 1] = b1; }
+      else {
+        // register-resident column: static index through a fully unrolled select (i is wave-uniform)
+#pragma unroll
+        for (int q = NMOT; q < KREG; q++) if (q == i) { B0[q] = b0; B1[q] = b1; }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = NMOT; q < KREG; q++) if (q >= NMOT + 3 * nc) { B0[q] = 0; B1[q] = 0; }
+  unsigned angmask = 0;
+  for (int c = 0; c < nc; c++) { const real* R = c < CL ? sh.b.crec[c] : ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC; if (R[5] < 0) angmask |= 1u << c; }
+  angmask = (unsigned)__builtin_amdgcn_readfirstlane((int)angmask);
+  if (lane < 9) sh.lrec[lane][3] = sh.lrec[lane][2] * sh.mrec[lane][0];          // (J W) dinv of the arm joint (1 up to rounding)
+  __threadfence_block();                                     // the streamed columns: written above, read back by the same lane
+  w.sync();
+  // ---- solve (every limit row in place)
+  // (the arm joints' three multipliers -- motor, lower, upper limit -- sit in lanes 0..8 of lam0 / lamlo / lamhi)
+  real lam0 = c0.lam0, lam1 = c1.lam0, lamlo = 0, lamhi = 0, z0, z1;
+  {
+    real v0 = 0, v1 = 0;                                     // warm start: z = lambda + rhs - dinv (J du) (see pgs_rows)
+    for (int c = 0; c < nc; c++) {
+      const int i = NMOT + 3 * c; const real l = sh.r_lam[3 * c];
+      real b0, b1;
+      if (i >= KREG) { b0 = Bg[(size_t)(i - KREG) * 128]; b1 = Bg[(size_t)(i - KREG) * 128 + 1]; }
+      else { b0 = 0; b1 = 0;
+#pragma unroll
+        for (int q = NMOT; q < KREG; q += 3) if (q == i) { b0 = B0[q]; b1 = B1[q]; } }
+      v0 += b0 * l; v1 += b1 * l;
+    }
+    z0 = c0.rhs + v0; z1 = c1.rhs + v1;
+  }
+  auto commit = [&](real& x, real y, int g) __attribute__((always_inline)) { commit_lane(x, y, g); };
+  auto iterate = [&](auto CHECKTAG) __attribute__((always_inline)) -> bool {
+    constexpr bool CHECK = decltype(CHECKTAG)::value;
+    unsigned long long busy = 0;
+    __asm__ volatile("" ::: "memory");
+    // ring of streamed columns: the first D are requested before the motor rows
+    int l8 = lane * 8;
+    __asm__ volatile("" : "+v"(l8));                       // (opaque once per iteration: the "+ 4" of the second word stays an immediate offset)
+    real r0[D], r1[D];
+#pragma unroll
+    for (int s = 0; s < D; s++) { const F2 t = ldcol(s, l8); r0[s] = t.x; r1[s] = t.y; }
+    constexpr int PF = 2;
+    real4 pa4[PF], pl4[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) { pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
+    real za = z0, zp = z0;
+#pragma unroll
+    for (int j = 0; j < PIH_OBJ_NJ; j++) {
+      if (j < 9) {
+        const real4 ca = pa4[j % PF], cl = pl4[j % PF];
+        if (j + PF < 9) { pa4[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[j + PF]); pl4[j % PF] = *reinterpret_cast<const real4*>(sh.lrec[j + PF]); }
+        const real rh = ca.y, th = ca.z, lim = ca.w;
+        const real lor = cl.x, hir = cl.y, wd = cl.w;
+        real y = -rdlane(za, j);
+        const real la = rdlane(lam0, j), ll = rdlane(lamlo, j), lh = rdlane(lamhi, j);
+        real sum = la + (rh - y);
+        sum = med3_(sum, -lim, lim);
+        const real dl = sum - la; commit(lam0, sum, j);
+        if (CHECK) busy |= __ballot(absr(dl) > th);
+        y += dl * wd;
+        real s2 = ll + (lor - y); s2 = max_(s2, (real)0);
+        const real d2 = s2 - ll; commit(lamlo, s2, j);
+        if (CHECK) busy |= __ballot(absr(d2) > th);
+        y += d2 * wd;
+        real s3 = lh + (hir + y); s3 = max_(s3, (real)0);
+        const real d3 = s3 - lh; commit(lamhi, s3, j);
+        if (CHECK) busy |= __ballot(absr(d3) > th);
+        const real tot = dl + d2 - d3;
+        za += B0[j] * tot; z1 += B1[j] * tot;
+      }
+      const int g = 9 + j;
+      const real cand = med3_(zp, c0.lb, c0.ub);
+      const real dlv = cand - lam0;
+      const real sdl = rdlane(dlv, g);
+      if (CHECK) busy |= __ballot(absr(dlv) > c0.thr) & (1ull << g);
+      commit(lam0, cand, g);
+      zp += B0[g] * sdl; z1 += B1[g] * sdl;
+    }
+    z0 = (za + zp) - z0;
+    // one row: clamp the lane's own z, take the row's step from its lane, move every z
+    auto rowstep = [&](int g, real lo0, real hi0, real lo1, real hi1, real b0, real b1) __attribute__((always_inline)) -> real {
+      real cand, dlv;
+      if (g < 64) { cand = med3_(z0, lo0, hi0); dlv = cand - lam0; if (CHECK) busy |= __ballot(absr(dlv) > c0.thr) & (1ull << g); }
+      else { cand = med3_(z1, lo1, hi1); dlv = cand - lam1; if (CHECK) busy |= __ballot(absr(dlv) > c1.thr) & (1ull << (g - 64)); }
+      const real sdl = rdlane(dlv, g & 63);
+      const real sc = rdlane(cand, g & 63);
+      if (g < 64) commit(lam0, cand, g); else commit(lam1, cand, g - 64);
+      z0 += b0 * sdl; z1 += b1 * sdl;
+      return sc;
+    };
+#pragma unroll
+    for (int c = 0; c < HC; c++) {
+      // (nc and angmask through opaque scalars: the 2 x 32 loop-invariant exit / friction conditions would otherwise be precomputed
+      //  as 64-bit lane masks outside the iteration loop and spilled to VGPR lanes)
+      int ncl = nc; unsigned am = angmask;
+      __asm__ volatile("" : "+s"(ncl), "+s"(am));
+      if (c >= ncl) break;
+      const int g0 = NMOT + 3 * c;
+      real b0[3], b1[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int i = g0 + k;
+        if (i < KREG) { b0[k] = B0[i < KREG ? i : 0]; b1[k] = B1[i < KREG ? i : 0]; }
+        else {
+          const int s = i - KREG;
+          b0[k] = r0[s % D]; b1[k] = r1[s % D];
+          const F2 t = ldcol(s + D, l8);                    // request the column a ring ahead (clamped: a harmless reload at the end)
+          r0[s % D] = t.x; r1[s % D] = t.y;
+        }
+      }
+      const real s0 = rowstep(g0, c0.lb, c0.ub, c1.lb, c1.ub, b0[0], b1[0]);
+      const bool loaded = s0 > 0 || ((am >> c) & 1u);
+      const real h0 = max_(c0.mu * s0, c0.fl), h1 = max_(c1.mu * s0, c1.fl);
+      const real fl0 = loaded ? -h0 : lam0, fh0 = loaded ? h0 : lam0, fl1 = loaded ? -h1 : lam1, fh1 = loaded ? h1 : lam1;
+      rowstep(g0 + 1, fl0, fh0, fl1, fh1, b0[1], b1[1]);
+      // (lam of the dir1 row has just changed: the collapsed bounds of an unloaded contact are per row)
+      const real gl0 = loaded ? -h0 : lam0, gh0 = loaded ? h0 : lam0, gl1 = loaded ? -h1 : lam1, gh1 = loaded ? h1 : lam1;
+      rowstep(g0 + 2, gl0, gh0, gl1, gh1, b0[2], b1[2]);
+    }
+    return CHECK && busy == 0;
+  };
+  const int it = pgs_iteration_loop(P.iters, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
+  if (lane == 0) sh.S[PIH_S_SOLVER] = 5;
+  // ---- multipliers back to LDS, DOF velocities du = sum_i W_i lambda_i
+  if (lane >= NMOT && lane < NMOT + 3 * nc) sh.r_lam[lane - NMOT] = lam0;
+  if (32 + lane < 3 * nc) sh.r_lam[32 + lane] = lam1;
+  if (lane < NMOT) sh.mrec[lane][1] = lane < 9 ? lam0 + lamlo - lamhi : lam0;
+  w.sync();
+  {
+    const int d = lane, dw = d < ND ? d : ND;
+    real du = 0;
+#pragma unroll
+    for (int j = 0; j < PIH_OBJ_NJ; j++) {
+      du += Mg[j * 64] * (d < 9 ? (j < 9 ? sh.mrec[j][1] : (real)0) : sh.mrec[9 + j][1]);
+    }
+    for (int r = 0; r < 3 * nc; r++) du += wp_row(sh, ov, r)[dw] * sh.r_lam[r];
+    if (d < ND) sh.u[d] += du;
+  }
+  w.sync();
+  return it;
+}
+
 // Sequential impulse, Bullet resolveSingleConstraintRowGeneric form; row order: per arm joint (motor, lower limit, upper
 // limit), the 23 pipe motors, then per contact (normal, dir1, dir2).  Returns iterations executed.
 // GPU form: one lane per DOF holds its entry of the velocity change `du`; row multipliers live lane-distributed in
@@ -553,6 +808,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
 PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW& mw) {
   const int nc = sh.nc;
   if (P.pgsmode == 0 && nc <= MERGED_CONTACTS) return pgs_rows(w, sh, P);   // all rows fit one wavefront: row-space solver
+  if (P.pgsmode == 0 && nc <= HC) return pgs_rows2(w, sh, P, ov, mw);       // two rows per lane
   if (w.lane() == 0) sh.S[PIH_S_SOLVER] = 0;
   // early exit test without divisions: (dl / dinv)^2 <= resid  <=>  dl^2 - resid dinv^2 <= 0  for every row
   w.sync();

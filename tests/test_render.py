@@ -95,7 +95,7 @@ def test_hip_render_matches_oracle():
         same = a[..., 1] == b[..., 1]
         assert same.mean() > 0.997                                  # silhouette pixels may flip class in fp32
         assert np.array_equal(a[..., 1], a[..., 2]) and np.array_equal(a[..., 1], a[..., 3])
-        assert np.abs(a[..., 0] - b[..., 0])[same].max() < 2e-6     # fp32 depth-buffer value
+        assert np.abs(a[..., 0] - b[..., 0])[same].max() < 5e-6     # fp32 depth-buffer value
         za = NEAR * FAR / (FAR - a[..., 0].astype(np.float64) * (FAR - NEAR)); zb = NEAR * FAR / (FAR - b[..., 0] * (FAR - NEAR))
         assert np.percentile(np.abs(za - zb)[same], 99) < 2e-4      # metres (fp32 resolution of 1 - near/z at z ~ 0.3 m)
         assert (a[..., 1] == 232.0).any()
