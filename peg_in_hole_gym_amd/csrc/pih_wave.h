@@ -422,7 +422,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
   if (lane < 9) sh.lrec[lane][3] = sh.lrec[lane][2] * sh.mrec[lane][0];          // (J W) dinv of the arm joint (1 up to rounding)
   w.sync();
   // ---- multipliers: arm rows wave-uniform in VGPRs, every other row in its own lane
-  real lam_a[9], lam_lo[9], lam_hi[9];
+  real lam_a[9], lam_lo[9], lam_hi[9], lamr[NMOT];     // pipe motor rows: wave-uniform multipliers (lam[g] += step: one issue slot)
   real lam = 0, z = 0;
   int it = 0;
   // commit one lane of a per-lane register: x[g] = y[g] (the lane mask is a compile-time constant in an SGPR pair)
@@ -431,6 +431,8 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
     constexpr bool FULL = decltype(FULLTAG)::value;
 #pragma unroll
     for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
+#pragma unroll
+    for (int g = 9; g < NMOT; g++) lamr[g] = 0;
     lam = lam0;
     {
       real v = 0;                          // warm start: J du of the cached normal multipliers, z = lambda + rhs - dinv (J du)
@@ -480,10 +482,10 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
         // pipe motor row 9 + j: every lane clamps its own z, the row's lane supplies the step
         const int g = 9 + j;
         const real cand = med3_(zp, lbv, ubv);
-        const real dlv = cand - lam;
+        const real dlv = cand - lamr[g];
         const real sdl = rdlane(dlv, g);
         if (CHECK) busy |= __ballot(absr(dlv) > thr) & (1ull << g);
-        commit(lam, cand, g);
+        lamr[g] += sdl;
         zp += Bn[g] * sdl;
       }
       z = (za + zp) - z;
@@ -526,7 +528,8 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
   if (lane == 0) sh.S[PIH_S_SOLVER] = (real)variant;
   // multipliers back to LDS: contacts -> r_lam, pipe motors -> word 1 of their (now unused) constant record
   if (lane >= NMOT && lane < NMOT + 3 * nc) sh.r_lam[lane - NMOT] = lam;
-  if (lane >= 9 && lane < NMOT) sh.mrec[lane][1] = lam;
+#pragma unroll
+  for (int g = 9; g < NMOT; g++) if (lane == 0) sh.mrec[g][1] = lamr[g];
   w.sync();
   {
     const int d = lane, dw = d < ND ? d : ND;

@@ -9,6 +9,8 @@ template <int VAR> __global__ void __launch_bounds__(64) k(float* out, long long
   float B[ROWS];
 #pragma unroll
   for (int i = 0; i < ROWS; i++) B[i] = 0.001f * (float)((lane * 7 + i * 13) % 17) - 0.008f;
+  unsigned long long mnext = 1; float ind[4] = {lane == 0 ? 1.f : 0.f, lane == 1 ? 1.f : 0.f, lane == 2 ? 1.f : 0.f, lane == 3 ? 1.f : 0.f};
+  __asm__ volatile("" : "+s"(mnext), "+v"(ind[0]), "+v"(ind[1]), "+v"(ind[2]), "+v"(ind[3]));
   long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -27,6 +29,24 @@ template <int VAR> __global__ void __launch_bounds__(64) k(float* out, long long
         z += B[g] * s;
       } else if (VAR == 3) {   // DPP row broadcast-ish substitute: quad_perm broadcast of lane 0 of each quad (timing of a DPP mov in the chain)
         const float s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dlv), 0x00, 0xF, 0xF, true));
+        z += B[g] * s;
+      } else if (VAR == 5) {   // commit mask made one row ahead (hides the SALU -> VALU latency)
+        const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlv), g));
+        __asm__ volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(lam) : "v"(cand), "s"(mnext));
+        __asm__ volatile("s_lshl_b64 %0, 1, %1" : "=s"(mnext) : "n"(1) : "scc");
+        z += B[g] * s;
+      } else if (VAR == 6) {   // commit through v_cmp_eq (VALU -> VCC -> v_cndmask)
+        const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlv), g));
+        lam = (lane == g) ? cand : lam;
+        z += B[g] * s;
+      } else if (VAR == 7) {   // commit through v_writelane of the broadcast candidate
+        const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlv), g));
+        const int sc = __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), g);
+        { int li = __builtin_bit_cast(int, lam); __asm__ volatile("v_writelane_b32 %0, %1, %2" : "+v"(li) : "s"(sc), "n"(0)); lam = __builtin_bit_cast(float, li); }
+        z += B[g] * s;
+      } else if (VAR == 8) {   // lam += dl at the row's lane through the broadcast step: lam = writelane(lam_g + s)... (readlane lam, add scalar? no SALU float) -> v_add on all lanes of a lane-masked step
+        const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlv), g));
+        lam += ind[g % 4] * s;   // indicator vectors (timing only)
         z += B[g] * s;
       } else if (VAR == 4) {   // v-space chain: readlane -> fma -> med3 -> sub -> fmac
         const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), g));
@@ -50,12 +70,16 @@ template <int VAR> void run(const char* name, float* out, long long* cyc, int bl
 }
 int main() { fprintf(stderr, "start\n");
   float* out; long long* cyc; hipMalloc(&out, 8192 * 64 * 4); hipMalloc(&cyc, 8192 * 8);
-  for (int blocks : {1, 2048, 4096}) {     // 1 wave alone; 2 / 4 / 8 waves per SIMD worth of work (1024 SIMDs)
+  for (int blocks : {1, 2048}) {     // 1 wave alone; 2 / 4 / 8 waves per SIMD worth of work (1024 SIMDs)
     run<0>("z-space row (readlane + commit)", out, cyc, blocks);
     run<2>("z-space row (readlane, no commit)", out, cyc, blocks);
     run<1>("no broadcast", out, cyc, blocks);
     run<3>("DPP mov instead of readlane", out, cyc, blocks);
     run<4>("v-space row", out, cyc, blocks);
+    run<5>("z-space, mask one row ahead", out, cyc, blocks);
+    run<6>("z-space, commit by v_cmp_eq + cndmask", out, cyc, blocks);
+    run<7>("z-space, commit by readlane + writelane", out, cyc, blocks);
+    run<8>("z-space, lam += indicator * step", out, cyc, blocks);
   }
   return 0;
 }
