@@ -332,9 +332,10 @@ def main():
 
     variants = None
     if env is not None and not fly:
-        v = st[:, 114].long().clamp(0, 4)
-        cnt = torch.bincount(v, minlength=5).float() / v.numel()
-        variants = dict(zip(["dof_space", "row_space_no_arm_limits", "row_space_arm_limits", "-", "row_space_rerun_all_limits"], [round(float(x), 4) for x in cnt]))
+        v = st[:, 114].long().clamp(0, 5)
+        cnt = torch.bincount(v, minlength=6).float() / v.numel()
+        variants = dict(zip(["dof_space", "row_space_no_arm_limits", "row_space_arm_limits", "-", "row_space_rerun_all_limits", "row_space_two_rows_per_lane"], [round(float(x), 4) for x in cnt]))
+        variants.pop("-")
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed if not args.dry_run else None

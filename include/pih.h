@@ -51,7 +51,8 @@ enum {
   PIH_S_ATTACH_QZ = 113,   /* scripted mode: z component of the grasped link's quaternion when the state machine entered state 4 (the
                               reference passes it as targetOrn[2] into childFrameOrientation, envs/peg_in_hole.py:101) */
   PIH_S_SOLVER = 114,      /* which PGS variant solved the last step: 0 DOF space, 1 / 2 row space without / with the limit rows of arm joints
-                              0..6, 4 row space re-run with all limit rows after an arm motor row clamped */
+                              0..6, 4 row space re-run with all limit rows after an arm motor row clamped, 5 row space with two rows per lane
+                              (11..32 contacts) */
   PIH_S_INVALID = 112,     /* 1: the state became non-finite while auto_reset = 0; the env was re-initialised, marked done and stays frozen until pih_reset */
   PIH_S_CACHE_N = 128, PIH_S_CACHE_KEY = 129, PIH_S_CACHE_LAMBDA = 129 + 48
 };

@@ -394,9 +394,10 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
 #pragma unroll
   for (int i = 0; i < FR; i++) { A[i] = (lane == i && lane >= 9 ? (real)1 : (real)0) - di * A[i]; }
   real* const Bn = A;
-  unsigned long long angmask = 0;          // contacts whose friction rows are always solved (mu < 0: the attach weld's rows)
+  unsigned angmask = 0;                    // contacts whose friction rows are always solved (mu < 0: the attach weld's rows)
 #pragma unroll
-  for (int c = 0; c < MERGED_CONTACTS; c++) if (c < nc && sh.b.crec[c][5] < 0) angmask |= 1ull << c;
+  for (int c = 0; c < MERGED_CONTACTS; c++) if (c < nc && sh.b.crec[c][5] < 0) angmask |= 1u << c;
+  angmask = (unsigned)__builtin_amdgcn_readfirstlane((int)angmask);
   // ---- the limit rows of arm joints 0..6 are exact no-ops for the whole solve when (a) the joint's motor row is never clamped --
   // an unclamped velocity motor sets the joint's velocity change to (target - current) whatever it was, because J W dinv = 1 -- and
   // (b) that target velocity violates neither limit speed: then  rhs_limit - (J du) dinv = (v_limit - v_target) dinv < 0  every time
@@ -493,7 +494,11 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       // unloaded contact alone: their bounds collapse onto the current multiplier (step 0) instead of a branch
 #pragma unroll
       for (int c = 0; c < MERGED_CONTACTS; c++) {
-        if (c >= nc) break;
+        // (nc and angmask through opaque scalars: the loop-invariant exit / friction conditions would otherwise be precomputed as
+        //  64-bit lane masks outside the iteration loop, spilled to VGPR lanes and read back with v_readlane in every iteration)
+        int ncl = nc; unsigned am = angmask;
+        __asm__ volatile("" : "+s"(ncl), "+s"(am));
+        if (c >= ncl) break;
         const int g0 = NMOT + 3 * c;
         const real cn = med3_(z, lbv, ubv);
         const real dn = cn - lam;
@@ -501,7 +506,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
         if (CHECK) busy |= __ballot(absr(dn) > thr) & (1ull << g0);
         commit(lam, cn, g0);
         z += Bn[g0] * sdn;
-        const bool loaded = s0 > 0 || ((angmask >> c) & 1ull);
+        const bool loaded = s0 > 0 || ((am >> c) & 1u);
         const real hi = max_(cmu * s0, cfl);
         const real fl = loaded ? -hi : lam, fh = loaded ? hi : lam;
         const real c1 = med3_(z, fl, fh);
