@@ -5,8 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from peg_in_hole_gym_amd.vec_env import PihVecEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+sched = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 for path in (0, 1):
-    env = PihVecEnv(n, auto_reset=1, debug=2, solver_path=path, max_episode_steps=2227)
+    env = PihVecEnv(n, auto_reset=1, debug=2, solver_path=path, max_episode_steps=2227, schedule=sched)
     gen = torch.Generator(device="cuda").manual_seed(1234)
     tot = []; pgs = []; cnt = []; smax = []; sarg = []; sph = []
     for t in range(460):
