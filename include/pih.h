@@ -151,6 +151,10 @@ int pih_ik_ur5(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev,
  * for envs env_begin .. env_begin+env_count-1, from the CURRENT state.  RGB is a flat value per object (table 153, pipe and
  * hole 232, fingers 77, background 255, the reference's uint8 scale): TinyRenderer's shading is not reproduced.  out_dev must be 16-byte aligned. */
 int pih_render(pih_handle* h, float* out_dev, int width, int height, int env_begin, int env_count, void* stream);
+/* the same with options: flags = PIH_RENDER_SHADED multiplies the per-object RGB value by ambient + diffuse x max(0, n . l) of
+ * TinyRenderer's default light (getCameraImage without light arguments; specular term and shadow map not reproduced) */
+#define PIH_RENDER_SHADED 1
+int pih_render_ex(pih_handle* h, float* out_dev, int width, int height, int env_begin, int env_count, int flags, void* stream);
 /* grasp-rectangle label images of random_grasp (envs/peg_in_hole.py:72-99,116) from the angle each env recorded when its
  * state machine entered state 2 (PIH_S_GRASP_ANGLE): out_dev float[env_count, 4, size, size] = pos (50 inside the rectangle),
  * sin(2 angle), cos(2 angle), width in pixels; meta_dev (may be NULL) float[env_count, 5] = x, y, angle [deg], width, length.

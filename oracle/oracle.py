@@ -138,10 +138,10 @@ class Oracle:
     def ncontacts(self):
         n = np.zeros(self.n, dtype=np.int32); self.L.piho_get_ncontacts(self.h, n.ctypes.data_as(C.POINTER(C.c_int32))); return n
 
-    def render(self, W=300, H=300):
+    def render(self, W=300, H=300, shaded=False):
         out = np.zeros((self.n, H, W, 4))
-        self.L.piho_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
-        self.L.piho_render(self.h, W, H, _dp(out)); return out
+        self.L.piho_render_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        self.L.piho_render_ex(self.h, W, H, 1 if shaded else 0, _dp(out)); return out
 
     def debug_contacts(self, env=0):
         out = np.zeros((CMAX, 12)); k = self.L.piho_debug_contacts(self.h, env, _dp(out)); return out[:k]

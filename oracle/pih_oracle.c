@@ -1044,8 +1044,13 @@ static real ray_tube(const v3 o, const v3 d) {   /* annular tube, axis x, centre
   }
   return best;
 }
-void piho_render(const piho_handle* h, int W, int H, real* out /* [n,H,W,4] */) {
+/* flags & 1: RGB shaded with the ambient + diffuse terms of TinyRenderer's defaults as getCameraImage drives it without light
+ * arguments [UNVERIFIED restatement; pybullet is absent: parity unpinned]: light direction (-50, 30, 100) normalised, ambient
+ * 0.6, diffuse 0.35; the specular term (0.05) and the shadow map are not reproduced. */
+void piho_render_ex(const piho_handle* h, int W, int H, int flags, real* out /* [n,H,W,4] */) {
   const real nearv = 0.001, farv = 1000.0, tanh2 = tan(0.5 * 60.0 * PI / 180.0);
+  const real lnorm = sqrt(50.0 * 50.0 + 30.0 * 30.0 + 100.0 * 100.0);
+  const v3 light = {-50.0 / lnorm, 30.0 / lnorm, 100.0 / lnorm};
   for (int e = 0; e < h->cfg.n_envs; e++) {
     const real* s = h->env[e].s;
     LinkKin K[NL];
@@ -1064,19 +1069,44 @@ void piho_render(const piho_handle* h, int W, int H, real* out /* [n,H,W,4] */) 
         real xc = (2.0 * (j + 0.5) / W - 1.0) * tanh2, yc = (1.0 - 2.0 * (i + 0.5) / H) * tanh2;   /* aspect 1 */
         v3 d = {xc, yc, -1.0}; real dn = v_norm(d); d[0] /= dn; d[1] /= dn; d[2] /= dn;
         real best = 1e30, col = 255.0;
+        int kind = 0, which = 0;
         const real tnear = nearv * dn;   /* ray parameter of the near plane: fragments in front of it are clipped (with closed
                                               fingers the eye lies ON the pad faces) */
-        if (d[2] < 0) { real t = (PIH_TABLE_Z - eye[2]) / d[2]; if (t >= tnear && t < best) { best = t; col = 153.0; } }
-        for (int sg = 0; sg < 24; sg++) { real t = ray_capsule(eye, d, vtx[sg], vtx[sg + 1], PIH_PIPE_RADIUS); if (t < best && t >= tnear) { best = t; col = 232.0; } }
-        { real t = ray_tube(eye, d); if (t < best && t >= tnear) { best = t; col = 232.0; } }
-        for (int f = 0; f < 2; f++) { real t = ray_box(eye, d, K[PIH_FINGER_LINK0 + f].R, fc[f], FBOX_H); if (t < best && t >= tnear) { best = t; col = 77.0; } }
+        if (d[2] < 0) { real t = (PIH_TABLE_Z - eye[2]) / d[2]; if (t >= tnear && t < best) { best = t; col = 153.0; kind = 1; } }
+        for (int sg = 0; sg < 24; sg++) { real t = ray_capsule(eye, d, vtx[sg], vtx[sg + 1], PIH_PIPE_RADIUS); if (t < best && t >= tnear) { best = t; col = 232.0; kind = 2; which = sg; } }
+        { real t = ray_tube(eye, d); if (t < best && t >= tnear) { best = t; col = 232.0; kind = 3; } }
+        for (int f = 0; f < 2; f++) { real t = ray_box(eye, d, K[PIH_FINGER_LINK0 + f].R, fc[f], FBOX_H); if (t < best && t >= tnear) { best = t; col = 77.0; kind = 4; which = f; } }
         real depth = 1.0;
         if (best < 1e29) { real z = best / dn; depth = farv * (z - nearv) / (z * (farv - nearv)); }   /* z = distance along the view axis */
+        if ((flags & 1) && kind != 0) {
+          v3 ph = {eye[0] + best * d[0], eye[1] + best * d[1], eye[2] + best * d[2]}, n = {0, 0, 1};
+          if (kind == 2) {
+            v3 ba, pa, r; v_sub(ba, vtx[which + 1], vtx[which]); v_sub(pa, ph, vtx[which]);
+            real q = v_dot(pa, ba) / fmax(v_dot(ba, ba), 1e-20); q = q < 0 ? 0 : (q > 1 ? 1 : q);
+            for (int k = 0; k < 3; k++) r[k] = pa[k] - q * ba[k];
+            real rn = fmax(v_norm(r), 1e-12); for (int k = 0; k < 3; k++) n[k] = r[k] / rn;
+          } else if (kind == 3) {
+            v3 oc; v_sub(oc, ph, HOLE_POS);
+            real rr = sqrt(oc[1] * oc[1] + oc[2] * oc[2]);
+            if (fabs(oc[0]) >= PIH_HOLE_HALFLEN - 1e-5) { n[0] = oc[0] > 0 ? 1 : -1; n[1] = 0; n[2] = 0; }
+            else { real sg = rr > 0.5 * (PIH_HOLE_RIN + PIH_HOLE_ROUT) ? 1.0 : -1.0, k = sg / fmax(rr, 1e-12); n[0] = 0; n[1] = oc[1] * k; n[2] = oc[2] * k; }
+          } else if (kind == 4) {
+            const real* R = K[PIH_FINGER_LINK0 + which].R;
+            v3 rel, pl; v_sub(rel, ph, fc[which]); m_tmulv(pl, R, rel);
+            real ax = fabs(pl[0]) / FBOX_H[0], ay = fabs(pl[1]) / FBOX_H[1], az = fabs(pl[2]) / FBOX_H[2];
+            v3 nl = {0, 0, 0};
+            if (ax >= ay && ax >= az) nl[0] = pl[0] > 0 ? 1 : -1; else if (ay >= az) nl[1] = pl[1] > 0 ? 1 : -1; else nl[2] = pl[2] > 0 ? 1 : -1;
+            m_mulv(n, R, nl);
+          }
+          real ndl = v_dot(n, light);
+          col = col * (0.6 + 0.35 * (ndl > 0 ? ndl : 0));
+        }
         real* px = img + ((size_t)i * W + j) * 4;
         px[0] = depth; px[1] = col; px[2] = col; px[3] = col;
       }
   }
 }
+void piho_render(const piho_handle* h, int W, int H, real* out /* [n,H,W,4] */) { piho_render_ex(h, W, H, 0, out); }
 
 /* Grasp-rectangle labels of random_grasp (envs/peg_in_hole.py:72-99): a length 0.1 x width 0.2 rectangle (image-relative)
  * centred on the image, rotated by `angle`, rasterised with skimage.draw.polygon, which is ABSENT here (parity unpinned):

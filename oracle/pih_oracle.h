@@ -79,6 +79,8 @@ void piho_get_ncontacts(const piho_handle* h, int32_t* out /* [n] */);
 
 /* PegInHole.render (envs/peg_in_hole.py:276-304) as an analytic ray caster: out [n,H,W,4] = depth, r, g, b */
 void piho_render(const piho_handle* h, int W, int H, piho_real* out);
+/* flags & 1: RGB shaded (ambient + diffuse of TinyRenderer's default light; see pih_oracle.c) */
+void piho_render_ex(const piho_handle* h, int W, int H, int flags, piho_real* out);
 /* grasp-rectangle label images of random_grasp (envs/peg_in_hole.py:72-99): out [4,S,S] = pos, sin, cos, wid; meta [5] */
 void piho_grasp_labels(piho_real angle, int S, piho_real* out, piho_real* meta);
 

@@ -19,7 +19,7 @@ TASK_PEG_IN_HOLE, TASK_RANDOM_FLY = 0, 1
 ABI_VERSION = 3
 
 EXPORTS = ["pih_default_config", "pih_abi_version", "pih_task_dims", "pih_create", "pih_destroy", "pih_reset", "pih_reseed", "pih_step", "pih_step_n",
-           "pih_get_state", "pih_set_state", "pih_ik", "pih_ik_ur5", "pih_render", "pih_grasp_labels", "pih_timing", "pih_timing2", "pih_set_timing", "pih_last_error"]
+           "pih_get_state", "pih_set_state", "pih_ik", "pih_ik_ur5", "pih_render", "pih_render_ex", "pih_grasp_labels", "pih_timing", "pih_timing2", "pih_set_timing", "pih_last_error"]
 
 
 class PihConfig(C.Structure):
@@ -66,6 +66,7 @@ def load():
     L.pih_ik.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.pih_ik_ur5.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.pih_render.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.pih_render_ex.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.pih_grasp_labels.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.pih_reseed.argtypes = [vp, C.c_uint64]
     L.pih_timing.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(64) pih_ik_ur5_kernel(Params P, int n, const f
 
 // wrist camera (p12): grid = (strips, envs), 256 threads (4 waves); out float[count, H, W, 4] = depth, r, g, b
 __global__ void __launch_bounds__(RENDER_THREADS) pih_render_kernel(const float* __restrict__ state, float* __restrict__ out,
-                                                                    int env_begin, int W, int H, int rows_per_strip) {
+                                                                    int env_begin, int W, int H, int rows_per_strip, int flags) {
   __shared__ Shared sh;
   __shared__ Scene sc;
   const int tid = threadIdx.x, e = blockIdx.y, env = env_begin + e;
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) pih_render_kernel(const float*
     if (j < j1) {
       const float xc = (sx * (j + 0.5f) - 1.0f) * T;
       for (int i = i0; i < i1; i++) {
-        real4 c = shade(sc, prims, xc, (1.0f - sy * (i + 0.5f)) * T);
+        real4 c = shade(sc, prims, xc, (1.0f - sy * (i + 0.5f)) * T, flags);
         img[i * W + j] = make_float4(c.x, c.y, c.z, c.w);
       }
     }
@@ -547,6 +547,10 @@ int pih_ik_ur5(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev,
 }
 
 int pih_render(pih_handle* h, float* out_dev, int width, int height, int env_begin, int env_count, void* stream) {
+  return pih_render_ex(h, out_dev, width, height, env_begin, env_count, 0, stream);
+}
+
+int pih_render_ex(pih_handle* h, float* out_dev, int width, int height, int env_begin, int env_count, int flags, void* stream) {
   if (!h || !out_dev || width <= 0 || height <= 0 || env_begin < 0 || env_count <= 0 || env_begin + env_count > h->cfg.n_envs) {
     if (h) h->err = "pih_render: bad arguments";
     return -2;
@@ -562,7 +566,7 @@ int pih_render(pih_handle* h, float* out_dev, int width, int height, int env_beg
   const int rows = ((height + strips - 1) / strips + 15) / 16 * 16;
   strips = (height + rows - 1) / rows;
   if (env_count > 65535) { h->err = "pih_render: env_count > 65535 per call"; return -2; }
-  hipLaunchKernelGGL(pih_render_kernel, dim3(strips, env_count), dim3(RENDER_THREADS), 0, (hipStream_t)stream, h->state, out_dev, env_begin, width, height, rows);
+  hipLaunchKernelGGL(pih_render_kernel, dim3(strips, env_count), dim3(RENDER_THREADS), 0, (hipStream_t)stream, h->state, out_dev, env_begin, width, height, rows, flags);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -4,8 +4,9 @@
 // aspect 1, near 0.001, far 1000, 300 x 300, result = concat(depth buffer, rgb).  With that target/up the camera basis is
 // world-axis aligned (side = +x, up = +y, forward = -z), so the ray through pixel (i, j) is (xc, yc, -1) in WORLD axes and
 // the eye-space depth of a hit is simply eye.z - hit.z.  The scene is the primitive set the physics uses: table plane,
-// 24 pipe capsules (r = 1 cm), the hole tube, the two finger-pad boxes.  TinyRenderer's shading is not reproduced: RGB is
-// one flat value per object (see oracle/pih_oracle.c piho_render, the checker of this file).
+// 24 pipe capsules (r = 1 cm), the hole tube, the two finger-pad boxes.  RGB: one flat value per object (flags = 0, the form the
+// parity tests compare class by class), or that value shaded with the ambient + diffuse terms of TinyRenderer's defaults
+// (PIH_RENDER_SHADED; see oracle/pih_oracle.c piho_render_ex, the checker of this file, for what is and is not reproduced).
 //
 // Mapping: one 256-thread workgroup per (env, strip of rows); the number of strips per env shrinks as the env count grows, so
 // that a full batch runs the forward kinematics once per env.  Each WAVE walks 16-row x 64-column pixel tiles of the strip:
@@ -36,6 +37,14 @@ struct Scene {
 #define PIH_COL_TABLE ((real)153)
 #define PIH_COL_PIPE ((real)232)
 #define PIH_COL_FINGER ((real)77)
+// TinyRenderer defaults as driven by getCameraImage without light arguments [UNVERIFIED restatement; pybullet is absent: parity
+// unpinned]: light direction (-50, 30, 100) normalised (z-up world), ambient 0.6, diffuse 0.35; the specular term (0.05) and the
+// shadow map are not reproduced
+#define PIH_LIGHT_X ((real)-0.43193421279068006)
+#define PIH_LIGHT_Y ((real)0.25916052767440806)
+#define PIH_LIGHT_Z ((real)0.86386842558136012)
+#define PIH_LIGHT_AMBIENT ((real)0.6)
+#define PIH_LIGHT_DIFFUSE ((real)0.35)
 
 PIH_HD real ray_sphere(V3 oc, V3 d, real r) {   // oc = eye - centre, d unit
   real b = dot(oc, d), c = dot(oc, oc) - r * r, disc = b * b - c;
@@ -165,36 +174,63 @@ PIH_HD bool prim_on_tile(const Scene& sc, int i, real tu0, real tu1, real tv0, r
 
 // one pixel: xc, yc = camera-plane coordinates of the pixel centre (already multiplied by tan(fov/2)); prims = bit i set if
 // primitive i may cover the pixel (wave-uniform)
-PIH_HD real4 shade(const Scene& sc, unsigned prims, real xc, real yc) {
+PIH_HD real4 shade(const Scene& sc, unsigned prims, real xc, real yc, int flags) {
   const V3 eye = ld3(sc.eye);
   real inv = rsqrt_((real)1 + xc * xc + yc * yc);
   V3 d = mk(xc * inv, yc * inv, -inv);
   real best = PIH_BIG, col = PIH_COL_BG;
+  int kind = 0, which = 0;                 // what the ray hit: 1 table, 2 capsule `which`, 3 tube, 4 finger box `which`
   const real tnear = PIH_CAM_NEAR / inv;   // ray parameter of the near plane: fragments in front of it are clipped (with closed
                                            // fingers the eye lies ON the pad faces: their hits at t ~ 0 must not be drawn)
   {
     real t = (PIH_TABLE_Z - eye.z) / d.z;
-    if (t >= tnear) { best = t; col = PIH_COL_TABLE; }
+    if (t >= tnear) { best = t; col = PIH_COL_TABLE; kind = 1; }
   }
   unsigned segs = prims & ((1u << NSEG) - 1u);
   while (segs) {
     const int sidx = __builtin_ctz(segs); segs &= segs - 1u;
     real t = ray_capsule(eye, d, ld3(sc.vtx[sidx]), ld3(sc.vtx[sidx + 1]), PIH_PIPE_RADIUS);
-    if (t < best && t >= tnear) { best = t; col = PIH_COL_PIPE; }
+    if (t < best && t >= tnear) { best = t; col = PIH_COL_PIPE; kind = 2; which = sidx; }
   }
   if (prims & (1u << (NSEG + 2))) {
     real t = ray_tube(eye, d);
-    if (t < best && t >= tnear) { best = t; col = PIH_COL_PIPE; }
+    if (t < best && t >= tnear) { best = t; col = PIH_COL_PIPE; kind = 3; }
   }
   for (int f = 0; f < 2; f++)
     if (prims & (1u << (NSEG + f))) {
       real t = ray_box(eye, d, ldm(sc.fR[f]), ld3(sc.fc[f]), ld3(FBOX_H));
-      if (t < best && t >= tnear) { best = t; col = PIH_COL_FINGER; }
+      if (t < best && t >= tnear) { best = t; col = PIH_COL_FINGER; kind = 4; which = f; }
     }
   real depth = 1;
   if (best < (real)1e29) {
     real z = best * inv;                 // eye-space depth = t * (-d.z)
     depth = PIH_CAM_FAR * (z - PIH_CAM_NEAR) / (z * (PIH_CAM_FAR - PIH_CAM_NEAR));
+  }
+  if ((flags & 1) && kind != 0) {
+    // surface normal at the hit point, Lambert term against the fixed light
+    const V3 ph = eye + best * d;
+    V3 n = mk(0, 0, 1);
+    if (kind == 2) {
+      const V3 a = ld3(sc.vtx[which]), ba = ld3(sc.vtx[which + 1]) - a;
+      real q = dot(ph - a, ba) / max_(dot(ba, ba), (real)1e-20);
+      q = q < 0 ? (real)0 : (q > 1 ? (real)1 : q);
+      const V3 r = ph - (a + q * ba);
+      n = ((real)1 / max_(norm(r), (real)1e-12)) * r;
+    } else if (kind == 3) {
+      const V3 oc = ph - ld3(HOLE_POS);
+      const real rr = (real)sqrt(oc.y * oc.y + oc.z * oc.z);
+      if (absr(oc.x) >= PIH_HOLE_HALFLEN - (real)1e-5) n = mk(oc.x > 0 ? (real)1 : (real)-1, 0, 0);
+      else { const real sgn = rr > (real)0.5 * (PIH_HOLE_RIN + PIH_HOLE_ROUT) ? (real)1 : (real)-1; const real k = sgn / max_(rr, (real)1e-12); n = mk(0, oc.y * k, oc.z * k); }
+    } else if (kind == 4) {
+      const M3 R = ldm(sc.fR[which]);
+      const V3 pl = tmul(R, ph - ld3(sc.fc[which])), h = ld3(FBOX_H);
+      const real ax = absr(pl.x) / h.x, ay = absr(pl.y) / h.y, az = absr(pl.z) / h.z;
+      V3 nl = mk(0, 0, 0);
+      if (ax >= ay && ax >= az) nl.x = pl.x > 0 ? (real)1 : (real)-1; else if (ay >= az) nl.y = pl.y > 0 ? (real)1 : (real)-1; else nl.z = pl.z > 0 ? (real)1 : (real)-1;
+      n = mul(R, nl);
+    }
+    const real ndl = n.x * PIH_LIGHT_X + n.y * PIH_LIGHT_Y + n.z * PIH_LIGHT_Z;
+    col = col * (PIH_LIGHT_AMBIENT + PIH_LIGHT_DIFFUSE * max_(ndl, (real)0));
   }
   real4 o; o.x = depth; o.y = col; o.z = col; o.w = col;
   return o;

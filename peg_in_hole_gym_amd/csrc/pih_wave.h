@@ -780,9 +780,8 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       const real h0 = max_(c0.mu * s0, c0.fl), h1 = max_(c1.mu * s0, c1.fl);
       const real fl0 = loaded ? -h0 : lam0, fh0 = loaded ? h0 : lam0, fl1 = loaded ? -h1 : lam1, fh1 = loaded ? h1 : lam1;
       rowstep(g0 + 1, fl0, fh0, fl1, fh1, b0[1], b1[1]);
-      // (lam of the dir1 row has just changed: the collapsed bounds of an unloaded contact are per row)
-      const real gl0 = loaded ? -h0 : lam0, gh0 = loaded ? h0 : lam0, gl1 = loaded ? -h1 : lam1, gh1 = loaded ? h1 : lam1;
-      rowstep(g0 + 2, gl0, gh0, gl1, gh1, b0[2], b1[2]);
+      // (the dir2 row's lane still holds its own multiplier: the bounds computed before the dir1 step remain valid in that lane)
+      rowstep(g0 + 2, fl0, fh0, fl1, fh1, b0[2], b1[2]);
     }
     return CHECK && busy == 0;
   };

@@ -50,7 +50,7 @@ def scripted_episode(backend, actions, n):
     (after exactly GRASP_IMG_STEP physics steps, :65-67), reward = q, done, info = [[pos, sin, cos, wid label images],
     [x, y, angle_deg, width, length]] (:116).  Returns (images [n,300,300,4], reward [n], done [n], infos)."""
     backend.step_n(GRASP_IMG_STEP, actions)
-    img = _to_numpy(backend.render(IMG_SHAPE[1], IMG_SHAPE[0])).astype(np.float64)
+    img = _to_numpy(backend.render(IMG_SHAPE[1], IMG_SHAPE[0], shaded=True)).astype(np.float64)
     rew = done = None
     for _ in range(8):
         _, rew, done = backend.step_n(320, actions)
@@ -119,7 +119,7 @@ class BaseEnv(object):
     def render(self, mode='rgb_array'):
         """envs/base_env.py:79-81 calls every agent's render and returns None; the images (PegInHole.render,
         envs/peg_in_hole.py:276-304) are kept in `self.images` ([task_num] arrays of [300,300,4] = depth, r, g, b)."""
-        img = _to_numpy(self._backend.render(IMG_SHAPE[1], IMG_SHAPE[0])).astype(np.float64)
+        img = _to_numpy(self._backend.render(IMG_SHAPE[1], IMG_SHAPE[0], shaded=True)).astype(np.float64)
         self.images = [img[i] for i in range(self.task_num)]
         return None
 

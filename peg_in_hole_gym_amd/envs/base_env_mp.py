@@ -102,7 +102,7 @@ class BaseEnvMp(object):
     def render(self, mode='rgb_array'):
         """envs/base_env_mp.py:66,85 forwards RENDER to every worker and returns None; the images are kept in
         `self.images` ([mp_num][sub_num] arrays of [300,300,4] = depth, r, g, b)."""
-        img = _to_numpy(self._backend.render(IMG_SHAPE[1], IMG_SHAPE[0])).astype(np.float64)
+        img = _to_numpy(self._backend.render(IMG_SHAPE[1], IMG_SHAPE[0], shaded=True)).astype(np.float64)
         self.images = self._nest([img[i] for i in range(self.n)])
         return None
 

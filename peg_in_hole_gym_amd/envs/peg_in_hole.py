@@ -89,7 +89,7 @@ class PegInHole(MetaEnv):
 
     def render(self, mode="rgb_array"):
         """PegInHole.render (envs/peg_in_hole.py:276-304): [300,300,4] = depth, r, g, b from the wrist camera"""
-        img = self._backend.render(300, 300)
+        img = self._backend.render(300, 300, shaded=True)
         return (img.detach().cpu().numpy() if hasattr(img, "detach") else np.asarray(img))[0].astype(np.float64)
 
 

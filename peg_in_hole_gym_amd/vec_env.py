@@ -142,14 +142,15 @@ class PihVecEnv:
             self._chk(self.L.pih_ik_ur5(self.h, n, q0.data_ptr(), tpos.data_ptr(), tquat.data_ptr(), out.data_ptr(), self._stream()), "pih_ik_ur5")
         return out
 
-    def render(self, width=300, height=300, env_begin=0, env_count=None, out=None):
+    def render(self, width=300, height=300, env_begin=0, env_count=None, out=None, shaded=False):
         """PegInHole.render (envs/peg_in_hole.py:276-304) for a block of envs: float32 [count, height, width, 4] =
-        (depth buffer, r, g, b) from the wrist camera at the current state (analytic ray caster, flat colours)."""
+        (depth buffer, r, g, b) from the wrist camera at the current state (analytic ray caster).  RGB is one flat value per
+        object, or (shaded=True) that value times ambient + diffuse of TinyRenderer's default light (pih_render_ex)."""
         count = self.n - env_begin if env_count is None else env_count
         if out is None:
             out = torch.empty(count, height, width, 4, device=self.device)
         with torch.cuda.device(self.device):
-            self._chk(self.L.pih_render(self.h, out.data_ptr(), width, height, env_begin, count, self._stream()), "pih_render")
+            self._chk(self.L.pih_render_ex(self.h, out.data_ptr(), width, height, env_begin, count, 1 if shaded else 0, self._stream()), "pih_render_ex")
         return out
 
     def grasp_labels(self, size=300, env_begin=0, env_count=None):

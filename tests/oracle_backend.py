@@ -55,8 +55,8 @@ class OracleBackend:
     def contact_force(self):
         return self.o.contact_force()
 
-    def render(self, width=300, height=300):
-        return self.o.render(width, height)
+    def render(self, width=300, height=300, shaded=False):
+        return self.o.render(width, height, shaded=shaded)
 
     def grasp_labels(self, size=300):
         ang = self.o.get_state()[:, 111]

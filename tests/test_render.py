@@ -2,7 +2,8 @@
 
 The reference renders with PyBullet's TinyRenderer, absent here: camera model and depth convention are pinned by closed
 forms (OpenGL projection of envs/peg_in_hole.py:276-293), the geometry is the primitive scene of this build, RGB is a flat
-value per object ("parity unpinned" against TinyRenderer's shading)."""
+value per object, optionally shaded with the ambient + diffuse terms of TinyRenderer's default light (restated constants,
+"parity unpinned" against TinyRenderer itself; specular term and shadow map not reproduced)."""
 import numpy as np
 import pytest
 
@@ -75,6 +76,47 @@ def test_grasp_labels_geometry(oracle_mod):
         major = v[:, 1]
         assert abs(abs(major @ np.array([np.sin(ang), np.cos(ang)])) - 1) < 2e-3
         assert np.allclose(lab[1][inside], np.sin(2 * ang)) and np.allclose(lab[2][~inside], 1.0)
+
+
+def test_shaded_rgb_known_answers(oracle_mod):
+    """Shaded RGB = flat object value x (0.6 + 0.35 max(0, n . l)), l = (-50, 30, 100) normalised: closed form on the table plane
+    (n = +z), bounds and left/right asymmetry on the pipe, depth and silhouettes identical to the flat image."""
+    O = oracle_mod
+    o = O.Oracle(1, mode=1, dv=0.05)
+    for _ in range(540):
+        o.step(np.zeros((1, 4)))
+    flat = o.render(120, 120)[0]; sh = o.render(120, 120, shaded=True)[0]
+    assert np.array_equal(flat[..., 0], sh[..., 0])                              # same depth buffer
+    lz = 100.0 / np.sqrt(50.0 ** 2 + 30.0 ** 2 + 100.0 ** 2)
+    table = flat[..., 1] == 153.0
+    assert table.any() and np.allclose(sh[..., 1][table], 153.0 * (0.6 + 0.35 * lz), atol=1e-9)
+    pipe = flat[..., 1] == 232.0
+    assert pipe.sum() > 50
+    v = sh[..., 1][pipe]
+    assert v.min() >= 232.0 * 0.6 - 1e-9 and v.max() <= 232.0 * 0.95 + 1e-9 and v.max() - v.min() > 10.0    # a lit and a dark flank
+    assert np.array_equal(sh[..., 1], sh[..., 2]) and np.array_equal(sh[..., 1], sh[..., 3])
+    bg = flat[..., 1] == 255.0
+    assert np.array_equal(sh[..., 1][bg], flat[..., 1][bg])                      # nothing hit: background value unchanged
+
+
+@pytest.mark.gpu
+def test_hip_shaded_render_matches_oracle():
+    import torch
+    from oracle import oracle as O
+    from peg_in_hole_gym_amd.vec_env import PihVecEnv
+    n = 4
+    g = PihVecEnv(n, mode=1, dv=0.05, seed=4)
+    g.step_n(540)
+    o = O.Oracle(n, mode=1, dv=0.05, seed=4)
+    o.set_state(g.state().cpu().numpy()[:, :128].astype(np.float64))
+    a = g.render(200, 160, shaded=True).cpu().numpy(); b = o.render(200, 160, shaded=True)
+    af = g.render(200, 160).cpu().numpy(); bf = o.render(200, 160)
+    assert np.array_equal(a[..., 0], af[..., 0])                                 # shading does not touch the depth buffer
+    same = af[..., 1] == bf[..., 1]                                              # pixels whose object class agrees
+    assert same.mean() > 0.997
+    d = np.abs(a[..., 1] - b[..., 1])[same]
+    assert np.percentile(d, 99) < 0.05 and np.median(d) < 1e-3                   # grey levels (0..255); normals at grazing hits differ in fp32
+    assert (a[..., 1][same] < af[..., 1][same] + 1e-3).all()                     # ambient + diffuse <= 0.95
 
 
 @pytest.mark.gpu

@@ -108,7 +108,9 @@ def test_facade_scripted_step_returns_camera_image_and_labels(oracle_mod):
     assert img.shape == (300, 300, 4) and done == [True]
     d = img[:, :, 0]
     assert 0.98 < d.min() <= d.max() <= 1.0
-    assert set(np.unique(img[:, :, 1])) <= {77.0, 153.0, 232.0, 255.0} and 232.0 in img[:, :, 1]     # the pipe is in view
+    # shaded RGB (the facade's image): every value is an object's grey level x [0.6, 0.95], or the background; the pipe is in view
+    g = img[:, :, 1]
+    assert ((g == 255.0) | ((g >= 77.0 * 0.6 - 1e-9) & (g <= 232.0 * 0.95 + 1e-9))).all() and ((g > 153.0 * 0.95 + 1e-6) & (g < 255.0)).any()
     (pos, sn, cs, wid), (x, y, ang, width, length) = info[0]
     assert pos.shape == (300, 300) and set(np.unique(pos)) == {0.0, 50.0}
     assert x == 0.0 and y == 0.0 and abs(width - 60.0) < 1e-9 and abs(length - 30.0) < 1e-9           # 0.2 * 300, 0.1 * 300
@@ -125,7 +127,7 @@ def test_facade_scripted_step_returns_camera_image_and_labels(oracle_mod):
     tip = o.tip_pose()[0]
     rv = oracle_mod.rotate_vector([0, o.get_state()[0, 90], 0], tip[3:7])
     assert abs(np.arctan2(rv[1], rv[0]) - a) < 1e-9
-    assert np.array_equal(o.render(300, 300)[0], img)
+    assert np.array_equal(o.render(300, 300, shaded=True)[0], img)      # the facade hands out the shaded image
 
 
 def _attach_frame_error(oracle_mod, s):

@@ -28,4 +28,19 @@ cd $R
 f=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1)
 head -8 "$f"
 cp "$f" $O/kernel_stats_$TAG.csv
+# the stats csv averages ALL launches of the run (300 pre-roll + 20 warm-up + 200 timed, contact load still rising); the average of the
+# LAST 200 launches in the kernel trace is the figure that must agree with bench.py's HIP-event average of the timed region
+python - "$O/prof_$TAG" "$O/kernel_trace_tail_$TAG.json" <<'PY'
+import csv, glob, json, sys
+rows = []
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "pih_step_kernel" in r["Kernel_Name"]:
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+rows.sort()
+tail = rows[-200:]
+out = {"kernel": "pih_step_kernel", "launches_in_trace": len(rows), "tail_launches": len(tail),
+       "tail_avg_ns": sum(e - s for s, e in tail) / max(1, len(tail)), "all_avg_ns": sum(e - s for s, e in rows) / max(1, len(rows))}
+json.dump(out, open(sys.argv[2], "w"), indent=1); print(json.dumps(out))
+PY
 find $O/prof_$TAG -name "*kernel_trace.csv" -delete
