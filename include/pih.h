@@ -103,8 +103,8 @@ typedef struct pih_config {
   int32_t enable_arm_collision; /* arm collision spheres (pih_model.h PIH_ARM_SPH_*): bit 0 vs the table plane, bit 1 vs the pipe (hand /
                                    flange / wrist spheres against the pipe's sample spheres); default 3 */
   int32_t task_id;            /* PIH_TASK_*: which task of TASK_LIST (envs/base_env.py:9-11) the handle simulates */
-  int32_t solver_path;        /* 0 (default): envs with <= 10 contacts use the row-space PGS (all rows in one wavefront), the others the DOF-space
-                                 PGS; 1: DOF-space PGS for every env (A/B runs and tests; same row sequence, results equal to rounding) */
+  int32_t solver_path;        /* 0 (default): row-space PGS -- one row per lane for <= 10 contacts, two rows per lane for 11..32 -- and the DOF-space
+                                 PGS beyond; 1: DOF-space PGS for every env (A/B runs and tests; same row sequence, results equal to rounding) */
   int32_t attach_ball;        /* p7 attach (createConstraint, envs/peg_in_hole.py:99-104): 0 (default) = 6-row weld honouring childFrameOrientation,
                                  1 = 3-row ball joint between the grasp point and the grasp-target origin (round-1 behaviour) */
   uint64_t seed;
