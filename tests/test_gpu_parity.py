@@ -181,16 +181,17 @@ def test_spill_path_many_contacts(torch_mod, oracle_mod):
 
 
 def test_row_space_and_dof_space_pgs_agree(torch_mod, oracle_mod):
-    """Envs with <= 10 contacts are solved in row space (pgs_rows: lane = row, Delassus row in registers), the others in DOF space;
-    solver_path = 1 forces DOF space for every env.  Same row sequence, so from identical states the two must agree to fp32
-    rounding; and both against the oracle.  The share of env-steps that took the row-space path is asserted."""
+    """Envs with <= 10 contacts are solved in row space with one row per lane (pgs_rows), 11..32 contacts with two rows per lane and
+    streamed matrix columns (pgs_rows2), the rest in DOF space; solver_path = 1 forces DOF space for every env.  Same row sequence, so
+    from identical states the two must agree to fp32 rounding; and both against the oracle.  The shares of env-steps that took each
+    row-space form are asserted (state word 114 = which solver ran), and the two-rows-per-lane steps are bounded on their own."""
     torch = torch_mod
     N = 256
     kw = dict(residual_threshold=0.0, seed=4)
     o = oracle_mod.Oracle(N, omp=True, warmstart=0.85, **kw)
     ga = _gpu(N, solver_path=0, **kw); gb = _gpu(N, solver_path=1, **kw)
     rng = np.random.default_rng(1)
-    dab, dao, lamd, fast = [], [], [], 0
+    dab, dao, lamd, fast, two, dab2, dao2 = [], [], [], 0, 0, [], []
     for t in range(160):
         a = rng.uniform(-1, 1, (N, 4))
         s = o.get_state()
@@ -202,13 +203,23 @@ def test_row_space_and_dof_space_pgs_agree(torch_mod, oracle_mod):
         sa = ga.state().cpu().numpy().astype(np.float64); sb = gb.state().cpu().numpy().astype(np.float64); so = o.get_state()
         np.testing.assert_array_equal(sa[:, 106], sb[:, 106])
         fast += int((sa[:, 106] <= 10).sum())
+        assert (sb[:, 114] == 0).all() and (sa[:, 114][sa[:, 106] <= 10] != 5).all() and (sa[:, 114][sa[:, 106] <= 10] != 0).all()
+        m2 = sa[:, 114] == 5
+        assert np.array_equal(m2, (sa[:, 106] > 10) & (sa[:, 106] <= 32))
+        two += int(m2.sum())
         dab.append(np.abs(sa[:, POS] - sb[:, POS]).max(1)); dao.append(np.abs(sa[:, POS] - so[:, POS]).max(1))
+        dab2.append(dab[-1][m2]); dao2.append(dao[-1][m2])
         lamd.append(np.abs(sa[:, 129 + 48:129 + 96] - sb[:, 129 + 48:129 + 96]).max(1))      # cached normal impulses
     dab = np.concatenate(dab); dao = np.concatenate(dao); lamd = np.concatenate(lamd)
     assert np.percentile(lamd, 99) < 2e-4 and (lamd > 5e-3).mean() < 2e-3        # rare ill-conditioned steps (tests/scenarios.py)
     print("row-space vs DOF-space PGS: %d of %d env-steps in row space; pose diff p50/p99/max %.2e / %.2e / %.2e ; vs oracle p50/p99 %.2e / %.2e" % (
         fast, N * 160, np.percentile(dab, 50), np.percentile(dab, 99), dab.max(), np.percentile(dao, 50), np.percentile(dao, 99)))
     assert fast > 0.5 * N * 160
+    dab2 = np.concatenate(dab2); dao2 = np.concatenate(dao2)
+    print("   two rows per lane: %d env-steps; pose diff vs DOF space p50/p99 %.2e / %.2e ; vs oracle p50/p99 %.2e / %.2e" % (
+        two, np.percentile(dab2, 50), np.percentile(dab2, 99), np.percentile(dao2, 50), np.percentile(dao2, 99)))
+    assert two > 300
+    assert np.percentile(dab2, 50) < 5e-6 and np.percentile(dab2, 90) < 2e-4
     assert np.percentile(dab, 50) < 2e-6 and np.percentile(dab, 99) < 2e-4
     assert np.percentile(dao, 50) < 5e-6 and np.percentile(dao, 99) < 2e-4
 
