@@ -335,26 +335,24 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       __asm__ volatile("" : "+v"(J[d]) :: "memory");     // one DOF at a time (same reason as for the columns of A below)
     }
   }
-  // ---- this lane's row of A: response rows broadcast from LDS (arm motor rows touch the 9 arm DOFs only, pipe motor rows the 29
-  // pipe DOFs only)
+  // ---- this lane's row of A.  Motor columns need no dot product: the Delassus matrix is symmetric, A[r][motor m] = (M^-1 J_r^T)[dof(m)]
+  // = W_r[dof(m)] -- a contact row reads entry dof(m) of its OWN response row, a motor row the entry of motor m's staged row at its
+  // own DOF (arm x pipe entries are 0): 32 LDS reads per lane instead of 748 FMAs + 748 broadcasts
   real A[FR];
+  {
+    const int row = lane - NMOT;                                         // contact-row index (lanes >= 32)
+    const bool crow = row >= 0 && row < 3 * nc;
+    const real* wown = crow ? sh.b.Wp[row] : sh.b.Wp[0];
 #pragma unroll
-  for (int g = 0; g < 9; g++) {
-    const real* wr = wma_row(sh, g); real a = 0;
-#pragma unroll
-    for (int d = 0; d < 9; d++) a += J[d] * wr[d];
-    // one column at a time: pin the sum HERE (an empty asm that "rewrites" it), otherwise the scheduler issues the LDS loads of all
-    // 62 columns first, spills them, and sinks the FMAs down to the first use of A
-    __asm__ volatile("" : "+v"(a) :: "memory");
-    A[g] = a;
-  }
-#pragma unroll
-  for (int g = 0; g < PIH_OBJ_NJ; g++) {
-    const real* wr = wmp_row(sh, g); real a = 0;
-#pragma unroll
-    for (int d = 9; d < ND; d++) a += J[d] * wr[d - 9];
-    __asm__ volatile("" : "+v"(a) :: "memory");
-    A[9 + g] = a;
+    for (int m = 0; m < NMOT; m++) {
+      const int dm = m < 9 ? m : 15 + (m - 9);                            // the motor's DOF
+      real a = 0;
+      if (crow) a = wown[dm];
+      else if (m < 9) { if (lane < 9) a = wma_row(sh, m)[lane]; }
+      else if (lane >= 9 && lane < NMOT) a = wmp_row(sh, m - 9)[lane - 3];   // DOF of pipe motor lane: 15 + (lane - 9); row entries start at DOF 9
+      __asm__ volatile("" : "+v"(a) :: "memory");
+      A[m] = a;
+    }
   }
 #pragma unroll
   for (int c = 0; c < MERGED_CONTACTS; c++) {
