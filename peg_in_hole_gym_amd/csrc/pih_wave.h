@@ -192,17 +192,10 @@ PIH_HD void aba_inward(Wave& w, Shared& sh, areal* rootp) {
     int s3 = l, s4 = l, s5 = l, s6 = l, s7 = l, s8 = l;
     if (typeA) { s3 = 8 * i + 3 + j1; s4 = 8 * (3 + i2) + 3 + j1; s5 = 8 * (3 + i1) + 3 + j1; s6 = 8 * i + 3 + j2; s7 = 8 * (3 + i2) + 3 + j2; s8 = 8 * (3 + i1) + 3 + j2; }
     const int sUj = j < 6 ? 8 * j : l;                                 // any lane of row j holds U_j
-    real carry = 0, hold = 0;
-    for (int L = NL - 1; L >= 0; L--) {
-      const int p = L_PARENT[L], jt = L_JTYPE[L];
-      const bool leaf = (L == NL - 1) || (L == ANL - 1) || (L == ANL - 2);
-      const real own = sh.a.IAP[L][own_off];
-      const real m = leaf ? own : own + carry;
-      if (jt == PIH_JT_FLOATING) {
-        w.sync(); if (l < 48) Mx[l] = m; w.sync();
-        aba_root_inverse(sh, Mx, rootp);
-        continue;
-      }
+    // one link with a joint (steps 2-4): stores U, 1/D, u; returns the lane's entry of what is handed up to the parent (garbage for
+    // the arm root, whose parent is the fixed world: `up` = false skips the translation)
+    auto link = [&](int L, real m, bool up) __attribute__((always_inline)) -> real {
+      const int jt = L_JTYPE[L];
       const int sb = jt == PIH_JT_REVOLUTE ? 0 : 3;
       const V3 a = ld3(sh.LA[L]);
       const real rA = m1 * sh.AR[L][kA], rB = m1 * sh.AR[L][kB], rG = m2 * sh.AR[L][j2], rK = m2 * sh.AR[L][j1];
@@ -217,17 +210,38 @@ PIH_HD void aba_inward(Wave& w, Shared& sh, areal* rootp) {
       const real Di = (real)1 / D;
       if (j == 0 && i < 6) sh.AU[L][i] = Ui;
       if (l == 0) { sh.ADinv[L] = Di; sh.Au[L] = u; }
-      if (p < 0) continue;   // arm root: parent is the fixed world
+      if (!up) return 0;
       real ma = j < 6 ? m - Ui * Uj * Di : m;                          // I^a ; column 6 is fixed up next
       const real s = sum8(j < 6 ? ma * cj : (real)0);                  // (I^a c)_i in every lane of row i
       if (j == 6) ma = m + s + Ui * (u * Di);                          // p^a = p^A + I^a c + U u / D
       const real X1 = from_lane(ma, 4 * s1), X2 = from_lane(ma, 4 * s2), X3 = from_lane(ma, 4 * s3), X4 = from_lane(ma, 4 * s4),
                  X5 = from_lane(ma, 4 * s5), X6 = from_lane(ma, 4 * s6), X7 = from_lane(ma, 4 * s7), X8 = from_lane(ma, 4 * s8);
-      const real v = ma + rA * X1 - rB * X2 - ((X3 + rA * X4 - rB * X5) * rG - (X6 + rA * X7 - rB * X8) * rK);
-      if (L == ANL - 1) hold = v;                                      // finger 8: park until finger 7 is done
-      else if (L == ANL - 2) carry = v + hold;                         // finger 7: both fingers feed link 6
-      else carry = v;
+      return ma + rA * X1 - rB * X2 - ((X3 + rA * X4 - rB * X5) * rG - (X6 + rA * X7 - rB * X8) * rK);
+    };
+    // The arm chain (links 8 .. 0) and the pipe chain (33 .. 9) are independent: the first eight steps take one link of each in
+    // the same basic block, so that the two dependent chains (LDS read -> DPP sums -> bpermute -> rcp -> DPP sums -> 8 bpermutes)
+    // fill each other's latencies; the remaining sixteen pipe links, the floating pipe root and the arm root follow.
+    real carry_p = 0, carry_a = 0, hold = 0;
+#pragma nounroll
+    for (int k = 0; k < 8; k++) {
+      const int Lp = NL - 1 - k, La = ANL - 1 - k;                     // pipe 33 .. 26, arm 8 .. 1
+      const real own_p = sh.a.IAP[Lp][own_off], own_a = sh.a.IAP[La][own_off];
+      const real mp = k == 0 ? own_p : own_p + carry_p;                // link 33 is the pipe's leaf
+      const real ma = k < 2 ? own_a : own_a + carry_a;                 // links 8 and 7 (the fingers) are leaves
+      const real vp = link(Lp, mp, true), va = link(La, ma, true);
+      carry_p = vp;
+      if (k == 0) hold = va;                                           // finger 8: parked until finger 7 is done
+      else if (k == 1) carry_a = va + hold;                            // finger 7: both fingers feed link 6
+      else carry_a = va;
     }
+#pragma nounroll
+    for (int L = NL - 9; L > ANL; L--) carry_p = link(L, sh.a.IAP[L][own_off] + carry_p, true);
+    {                                                                  // floating pipe root
+      const real m = sh.a.IAP[ANL][own_off] + carry_p;
+      w.sync(); if (l < 48) Mx[l] = m; w.sync();
+      aba_root_inverse(sh, Mx, rootp);
+    }
+    link(0, sh.a.IAP[0][own_off] + carry_a, false);                    // arm root: parent is the fixed world
     w.sync();
   }
 }
