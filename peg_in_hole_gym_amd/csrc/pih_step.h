@@ -45,32 +45,40 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
   areal rootp[6] = {0, 0, 0, 0, 0, 0};
   aba_inward(w, sh, rootp);
   w.stamp(10);
-  // outward sweep: accelerations (wave-uniform).  VW/VV are reused to carry (alpha, acc) of each link.
+  // outward sweep: accelerations (wave-uniform).  The arm chain and the pipe chain are independent: after the floating pipe root, arm
+  // link k and pipe link 10 + k advance in the same basic block (two dependent chains fill each other's latencies), the remaining
+  // pipe links follow.
   {
-    V3 alp = mk(0, 0, 0), acp = mk(0, 0, 0), al6 = alp, ac6 = acp;   // parent's (alpha, acc) in registers
-    for (int L = 0; L < NL; L++) {
-      int jt = L_JTYPE[L], d = link_dof(L);
-      V3 al, ac;
-      if (jt == PIH_JT_FLOATING) {
-        real x[6];
-        for (int i = 0; i < 6; i++) { real sacc = 0; for (int j = 0; j < 6; j++) sacc -= sh.Inv6[6 * i + j] * (real)rootp[j]; x[i] = sacc; }
-        al = mk(x[0], x[1], x[2]); ac = mk(x[3], x[4], x[5]);
-        sh.udot[d] = ac.x; sh.udot[d + 1] = ac.y; sh.udot[d + 2] = ac.z; sh.udot[d + 3] = al.x; sh.udot[d + 4] = al.y; sh.udot[d + 5] = al.z;
-      } else {
-        if (L == 0) { alp = mk(0, 0, 0); acp = mk(0, 0, 0); }
-        if (L == ANL - 1) { alp = al6; acp = ac6; }
-        V3 r = ld3(sh.AR[L]);
-        V3 aa = alp + ld3(sh.a.CB[L]);
-        V3 ll = acp + cross(alp, r) + ld3(sh.a.CB[L] + 3);
-        V3 Ua = ld3(sh.AU[L]), Ul = ld3(sh.AU[L] + 3);
-        real qdd = (sh.Au[L] - dot(Ua, aa) - dot(Ul, ll)) * sh.ADinv[L];
-        V3 a = ld3(sh.LA[L]);
-        if (jt == PIH_JT_REVOLUTE) { al = aa + qdd * a; ac = ll; } else { al = aa; ac = ll + qdd * a; }
-        sh.udot[d] = qdd;
-      }
-      alp = al; acp = ac;
-      if (L == ANL - 3) { al6 = al; ac6 = ac; }
+    struct Acc { V3 al, ac; };
+    auto olink = [&](int L, const Acc& par) __attribute__((always_inline)) -> Acc {
+      const int jt = L_JTYPE[L], d = link_dof(L);
+      V3 r = ld3(sh.AR[L]);
+      V3 aa = par.al + ld3(sh.a.CB[L]);
+      V3 ll = par.ac + cross(par.al, r) + ld3(sh.a.CB[L] + 3);
+      V3 Ua = ld3(sh.AU[L]), Ul = ld3(sh.AU[L] + 3);
+      real qdd = (sh.Au[L] - dot(Ua, aa) - dot(Ul, ll)) * sh.ADinv[L];
+      V3 a = ld3(sh.LA[L]);
+      Acc o;
+      if (jt == PIH_JT_REVOLUTE) { o.al = aa + qdd * a; o.ac = ll; } else { o.al = aa; o.ac = ll + qdd * a; }
+      sh.udot[d] = qdd;
+      return o;
+    };
+    Acc pipe, arm, arm6;
+    {                                                                  // floating pipe root (link ANL)
+      const int d = link_dof(ANL);
+      real x[6];
+      for (int i = 0; i < 6; i++) { real sacc = 0; for (int j = 0; j < 6; j++) sacc -= sh.Inv6[6 * i + j] * (real)rootp[j]; x[i] = sacc; }
+      pipe.al = mk(x[0], x[1], x[2]); pipe.ac = mk(x[3], x[4], x[5]);
+      sh.udot[d] = pipe.ac.x; sh.udot[d + 1] = pipe.ac.y; sh.udot[d + 2] = pipe.ac.z; sh.udot[d + 3] = pipe.al.x; sh.udot[d + 4] = pipe.al.y; sh.udot[d + 5] = pipe.al.z;
     }
+    arm.al = mk(0, 0, 0); arm.ac = mk(0, 0, 0); arm6 = arm;            // the arm's parent is the fixed world
+    for (int k = 0; k < ANL; k++) {
+      const Acc pa = k == ANL - 1 ? arm6 : arm;                        // the second finger hangs on link 6 like the first
+      const Acc na = olink(k, pa), np = olink(ANL + 1 + k, pipe);
+      arm = na; pipe = np;
+      if (k == ANL - 3) arm6 = na;
+    }
+    for (int L = 2 * ANL + 1; L < NL; L++) pipe = olink(L, pipe);
   }
 }
 
