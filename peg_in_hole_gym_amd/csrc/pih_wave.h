@@ -503,7 +503,8 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       }
       z = (za + zp) - z;
       // contacts: normal, dir1, dir2 -- the friction bounds follow the normal multiplier; Bullet leaves the friction rows of an
-      // unloaded contact alone: their bounds collapse onto the current multiplier (step 0) instead of a branch
+      // unloaded contact alone: a wave-uniform branch (half of the listed contacts are unloaded; collapsing their bounds onto the
+      // current multiplier instead -- branch-free, step 0 -- costs the 14 VALU of two rows for nothing: 263 k vs 247 k cycles at 8-10)
 #pragma unroll
       for (int c = 0; c < MERGED_CONTACTS; c++) {
         // (nc and angmask through opaque scalars: the loop-invariant exit / friction conditions would otherwise be precomputed as
@@ -519,20 +520,21 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
         commit(lam, cn, g0);
         z += Bn[g0] * sdn;
         const bool loaded = s0 > 0 || ((am >> c) & 1u);
-        const real hi = max_(cmu * s0, cfl);
-        const real fl = loaded ? -hi : lam, fh = loaded ? hi : lam;
-        const real c1 = med3_(z, fl, fh);
-        const real d1 = c1 - lam;
-        const real sd1 = rdlane(d1, g0 + 1);
-        if (CHECK) busy |= __ballot(absr(d1) > thr) & (1ull << (g0 + 1));
-        commit(lam, c1, g0 + 1);
-        z += Bn[g0 + 1] * sd1;
-        const real c2 = med3_(z, fl, fh);
-        const real d2 = c2 - lam;
-        const real sd2 = rdlane(d2, g0 + 2);
-        if (CHECK) busy |= __ballot(absr(d2) > thr) & (1ull << (g0 + 2));
-        commit(lam, c2, g0 + 2);
-        z += Bn[g0 + 2] * sd2;
+        if (loaded) {                                   // wave-uniform (Bullet leaves the friction rows of an unloaded contact alone)
+          const real hi = max_(cmu * s0, cfl);
+          const real c1 = med3_(z, -hi, hi);
+          const real d1 = c1 - lam;
+          const real sd1 = rdlane(d1, g0 + 1);
+          if (CHECK) busy |= __ballot(absr(d1) > thr) & (1ull << (g0 + 1));
+          commit(lam, c1, g0 + 1);
+          z += Bn[g0 + 1] * sd1;
+          const real c2 = med3_(z, -hi, hi);
+          const real d2 = c2 - lam;
+          const real sd2 = rdlane(d2, g0 + 2);
+          if (CHECK) busy |= __ballot(absr(d2) > thr) & (1ull << (g0 + 2));
+          commit(lam, c2, g0 + 2);
+          z += Bn[g0 + 2] * sd2;
+        }
       }
       return CHECK && busy == 0;
     };
@@ -789,11 +791,11 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       }
       const real s0 = rowstep(g0, c0.lb, c0.ub, c1.lb, c1.ub, b0[0], b1[0]);
       const bool loaded = s0 > 0 || ((am >> c) & 1u);
-      const real h0 = max_(c0.mu * s0, c0.fl), h1 = max_(c1.mu * s0, c1.fl);
-      const real fl0 = loaded ? -h0 : lam0, fh0 = loaded ? h0 : lam0, fl1 = loaded ? -h1 : lam1, fh1 = loaded ? h1 : lam1;
-      rowstep(g0 + 1, fl0, fh0, fl1, fh1, b0[1], b1[1]);
-      // (the dir2 row's lane still holds its own multiplier: the bounds computed before the dir1 step remain valid in that lane)
-      rowstep(g0 + 2, fl0, fh0, fl1, fh1, b0[2], b1[2]);
+      if (loaded) {                                        // wave-uniform (Bullet leaves the friction rows of an unloaded contact alone)
+        const real h0 = max_(c0.mu * s0, c0.fl), h1 = max_(c1.mu * s0, c1.fl);
+        rowstep(g0 + 1, -h0, h0, -h1, h1, b0[1], b1[1]);
+        rowstep(g0 + 2, -h0, h0, -h1, h1, b0[2], b1[2]);
+      }
     }
     return CHECK && busy == 0;
   };
