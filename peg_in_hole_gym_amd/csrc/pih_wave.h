@@ -311,17 +311,22 @@ PIH_HD void row16_sum3(real& a, real& b, real& c) {
 // env that would have met the threshold between two checks performs at most 7 extra iterations whose updates are all below the
 // threshold; with residual_threshold = 0 (every parity test) nothing changes.  The unchecked body is instantiated twice per trip:
 // the multipliers are loop-carried, and with a single copy every new value is moved back into the register the loop header expects.
-template <class FC, class FN> PIH_HD int pgs_iteration_loop(int iters, FC checked, FN unchecked) {
+template <bool DOUBLED = true, class FC, class FN> PIH_HD int pgs_iteration_loop(int iters, FC checked, FN unchecked) {
   int it = 0;
   // iterations 1..4 with the test
   while (it < iters && it < 4) { it++; if (checked()) return it; }
   // then groups of eight: seven without, one with (the last iteration always with)
   while (it < iters) {
     const int stop = it + 7 < iters - 1 ? it + 7 : iters - 1;
-    while (it < stop) {
-      it++; unchecked();
-      if (it >= stop) break;
-      it++; unchecked();
+    if (DOUBLED) {
+      while (it < stop) {
+        it++; unchecked();
+        if (it >= stop) break;
+        it++; unchecked();
+      }
+    } else {
+#pragma nounroll
+      while (it < stop) { it++; unchecked(); }
     }
     it++; if (checked()) return it;
   }
@@ -799,7 +804,7 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
     }
     return CHECK && busy == 0;
   };
-  const int it = pgs_iteration_loop(P.iters, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
+  const int it = pgs_iteration_loop<false>(P.iters, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
   if (lane == 0) sh.S[PIH_S_SOLVER] = 5;
   // ---- multipliers back to LDS, DOF velocities du = sum_i W_i lambda_i
   if (lane >= NMOT && lane < NMOT + 3 * nc) sh.r_lam[lane - NMOT] = lam0;
