@@ -306,18 +306,18 @@ PIH_HD void row16_sum3(real& a, real& b, real& c) {
 // velocities are recovered at the end as du = sum_i W_i lambda_i.  The arm-row and pipe-row columns are disjoint (A[arm][pipe
 // motor] = 0), so the motor chain runs on two accumulators for ILP exactly like the DOF-space chain.
 // The iteration loop of both solvers.  Bullet's early exit (largest squared row residual <= 1e-7) is evaluated in the first four
-// iterations -- where it actually fires: envs in free flight converge in two -- and after that in every 8th iteration and in the
+// iterations -- where it actually fires: envs in free flight converge in two -- and after that in every 16th iteration and in the
 // last one; in between the body runs without the per-row compare (one v_cmp + one scalar OR per row, ~15 % of a row update).  An
-// env that would have met the threshold between two checks performs at most 7 extra iterations whose updates are all below the
+// env that would have met the threshold between two checks performs at most 15 extra iterations whose updates are all below the
 // threshold; with residual_threshold = 0 (every parity test) nothing changes.  The unchecked body is instantiated twice per trip:
 // the multipliers are loop-carried, and with a single copy every new value is moved back into the register the loop header expects.
 template <bool DOUBLED = true, class FC, class FN> PIH_HD int pgs_iteration_loop(int iters, FC checked, FN unchecked) {
   int it = 0;
   // iterations 1..4 with the test
   while (it < iters && it < 4) { it++; if (checked()) return it; }
-  // then groups of eight: seven without, one with (the last iteration always with)
+  // then groups of sixteen: fifteen without, one with (the last iteration always with)
   while (it < iters) {
-    const int stop = it + 7 < iters - 1 ? it + 7 : iters - 1;
+    const int stop = it + 15 < iters - 1 ? it + 15 : iters - 1;
     if (DOUBLED) {
       while (it < stop) {
         it++; unchecked();
