@@ -294,17 +294,19 @@ PIH_HD void row16_sum3(real& a, real& b, real& c) {
 }
 
 
-// ---- PGS in ROW space for envs with few contacts (the common case: 80 % of the env-steps of the benchmark workload)
+// ---- PGS in ROW space for envs with few contacts (the common case: 70-80 % of the env-steps of the benchmark workload)
 // When all rows fit one wavefront -- 32 motor rows + 3 x (<= MERGED_CONTACTS) contact rows <= 62 -- lane g owns row g and holds
-//   v = J_g . du            the velocity change along its own row caused by every impulse applied so far, and
-//   A[i] = J_g . W_i        the response of its row to a unit impulse of row i, for EVERY row i (62 registers: the lane's row of the
-//                           Delassus matrix J M^-1 J^T, built once per step from the response rows that build_rows staged in LDS).
-// A row update then needs no Jacobian and no cross-lane reduction at all: one v_readlane (v of the row), the clamp chain in
-// wave-uniform VGPRs, and ONE FMA per row (v += A[i] * d lambda) -- 3 readlane + ~20 + 3 FMA per contact instead of the 87
-// instructions of the DOF-space block (on-the-fly Jacobian columns + three 38-lane DPP reductions), with the same sequence of
-// row updates as Bullet (per arm joint: motor, lower, upper limit; the 23 pipe motors; per contact: normal, dir1, dir2).  The DOF
-// velocities are recovered at the end as du = sum_i W_i lambda_i.  The arm-row and pipe-row columns are disjoint (A[arm][pipe
-// motor] = 0), so the motor chain runs on two accumulators for ILP exactly like the DOF-space chain.
+//   z = lambda + rhs - dinv (J_g . du)   "the multiplier the row would take if it were not clamped", given every impulse applied so
+//                                        far (the arm joints' lanes, whose three rows share one lane, hold -dinv (J_g . du)), and
+//   Bn[i] = [g == i] - dinv A[g][i]      from the lane's row of the Delassus matrix A = J M^-1 J^T, for EVERY row i (62 registers;
+//                                        motor columns by symmetry from the lane's own response row, contact columns as J_g . W_i
+//                                        against the response rows that build_rows staged in LDS).
+// A row update then needs no Jacobian and no cross-lane reduction: every lane clamps its own z (v_med3), subtracts its multiplier,
+// the row's lane supplies the step through one v_readlane, and ONE FMA moves every z (z += Bn[i] * step; the updated row's own z
+// stays put because dinv A[i][i] = 1) -- with the same sequence of row updates as Bullet (per arm joint: motor, lower, upper
+// limit; the 23 pipe motors; per contact: normal, dir1, dir2).  The DOF velocities are recovered at the end as du = sum_i W_i
+// lambda_i.  The arm-row and pipe-row columns are disjoint (A[arm][pipe motor] = 0), so the motor chain runs on two accumulators
+// for ILP exactly like the DOF-space chain.  (tools/micro/rowchain.hip times the row chain in isolation.)
 // The iteration loop of both solvers.  Bullet's early exit (largest squared row residual <= 1e-7) is evaluated in the first four
 // iterations -- where it actually fires: envs in free flight converge in two -- and after that in every 16th iteration and in the
 // last one; in between the body runs without the per-row compare (one v_cmp + one scalar OR per row, ~15 % of a row update).  An
