@@ -80,6 +80,8 @@ PIH_CONST int FSM_STEPS[10] = PIH_FSM_STEPS;
 #define PIH_MAX_COORD_VEL ((real)100)
 #define PIH_MAX_FRICTION ((real)10)
 #define PIH_BIG ((real)1e30)
+// compiler-only memory barrier (no instruction): bounds how far the scheduler may move LDS reads
+#define PIH_MEM_FENCE() __asm__ volatile("" ::: "memory")
 
 // Accumulator type of the articulated-inertia sweep.  Measured (tests/emul, f32 vs f32a builds): keeping this sweep in
 // fp64 halves the fp32 error of the free acceleration (1e-5 -> 5e-6 relative) but leaves the one-step pose / contact-force
@@ -703,55 +705,85 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
   bool arm = (la >= 0 && la < ANL) || (lb >= 0 && lb < ANL) || (jm >= 0 && jm < ANL);
   bool obj = (la >= ANL) || (lb >= ANL) || (jm >= ANL);
   if (arm && out.wa) {
+    // (same treatment as the pipe sweep below: impulse terms formed once, link constants one link ahead, results stored at the end)
+    const bool aa_ = la >= 0 && la < ANL, ab_ = lb >= 0 && lb < ANL;
+    const V3 rA = p - ld3(sh.LO[aa_ ? la : 0]), rB = p - ld3(sh.LO[ab_ ? lb : 0]);
+    const V3 tqa = ang ? dir : cross(rA, dir), tqb = ang ? dir : cross(rB, dir), tl = ang ? mk(0, 0, 0) : dir;
+    struct LinkC { V3 a, Ua, Ul, r; real Di; };
+    auto linkc = [&](int L) __attribute__((always_inline)) -> LinkC {
+      LinkC c; c.a = ld3(sh.LA[L]); c.Ua = ld3(sh.AU[L]); c.Ul = ld3(sh.AU[L] + 3); c.r = ld3(sh.AR[L]); c.Di = sh.ADinv[L]; return c;
+    };
     V3 Qa[ANL], Ql[ANL]; real uu[ANL];
 #pragma unroll
     for (int L = 0; L < ANL; L++) { Qa[L] = mk(0, 0, 0); Ql[L] = mk(0, 0, 0); }
+    LinkC nx = linkc(ANL - 1);
 #pragma unroll
     for (int L = ANL - 1; L >= 0; L--) {
-      if (L == la) { Qa[L] = Qa[L] + (ang ? dir : cross(p - ld3(sh.LO[L]), dir)); Ql[L] = Ql[L] + (ang ? mk(0, 0, 0) : dir); }
-      if (L == lb) { Qa[L] = Qa[L] - (ang ? dir : cross(p - ld3(sh.LO[L]), dir)); Ql[L] = Ql[L] - (ang ? mk(0, 0, 0) : dir); }
-      V3 a = ld3(sh.LA[L]);
+      const LinkC c = nx;
+      if (L > 0) nx = linkc(L - 1);
+      if (L == la) { Qa[L] = Qa[L] + tqa; Ql[L] = Ql[L] + tl; }
+      if (L == lb) { Qa[L] = Qa[L] - tqb; Ql[L] = Ql[L] - tl; }
       constexpr int JT[ANL] = {0, 0, 0, 0, 0, 0, 0, 1, 1};
       constexpr int PAR[ANL] = {-1, 0, 1, 2, 3, 4, 5, 6, 6};
-      real u = (L == jm ? (real)1 : (real)0) + (JT[L] == 0 ? dot(a, Qa[L]) : dot(a, Ql[L]));
+      real u = (L == jm ? (real)1 : (real)0) + (JT[L] == 0 ? dot(c.a, Qa[L]) : dot(c.a, Ql[L]));
       uu[L] = u;
       if (PAR[L] >= 0) {
-        real ud = u * sh.ADinv[L];
-        V3 qa = Qa[L] - ud * ld3(sh.AU[L]), ql = Ql[L] - ud * ld3(sh.AU[L] + 3);
-        Qa[PAR[L]] = Qa[PAR[L]] + qa + cross(ld3(sh.AR[L]), ql); Ql[PAR[L]] = Ql[PAR[L]] + ql;
+        real ud = u * c.Di;
+        V3 qa = Qa[L] - ud * c.Ua, ql = Ql[L] - ud * c.Ul;
+        Qa[PAR[L]] = Qa[PAR[L]] + qa + cross(c.r, ql); Ql[PAR[L]] = Ql[PAR[L]] + ql;
       }
+      PIH_MEM_FENCE();
     }
-    V3 dw[ANL], dvv[ANL];
+    V3 dw[ANL], dvv[ANL]; real wq[ANL];
+    nx = linkc(0);
 #pragma unroll
     for (int L = 0; L < ANL; L++) {
+      const LinkC c = nx;
+      if (L + 1 < ANL) nx = linkc(L + 1);
       constexpr int JT[ANL] = {0, 0, 0, 0, 0, 0, 0, 1, 1};
       constexpr int PAR[ANL] = {-1, 0, 1, 2, 3, 4, 5, 6, 6};
       V3 aa = mk(0, 0, 0), ll = mk(0, 0, 0);
-      if (PAR[L] >= 0) { aa = dw[PAR[L]]; ll = dvv[PAR[L]] + cross(aa, ld3(sh.AR[L])); }
-      real dq = (uu[L] - dot(ld3(sh.AU[L]), aa) - dot(ld3(sh.AU[L] + 3), ll)) * sh.ADinv[L];
-      V3 a = ld3(sh.LA[L]);
-      if (JT[L] == 0) { dw[L] = aa + dq * a; dvv[L] = ll; } else { dw[L] = aa; dvv[L] = ll + dq * a; }
-      out.wa[L] = dq;
+      if (PAR[L] >= 0) { aa = dw[PAR[L]]; ll = dvv[PAR[L]] + cross(aa, c.r); }
+      real dq = (uu[L] - dot(c.Ua, aa) - dot(c.Ul, ll)) * c.Di;
+      if (JT[L] == 0) { dw[L] = aa + dq * c.a; dvv[L] = ll; } else { dw[L] = aa; dvv[L] = ll + dq * c.a; }
+      wq[L] = dq;
       if (L == jm) jw += dq;
-      if (L == la) dvp = dvp + (ang ? dw[L] : dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
-      if (L == lb) dvp = dvp - (ang ? dw[L] : dvv[L] + cross(dw[L], p - ld3(sh.LO[L])));
+      if (L == la) dvp = dvp + (ang ? dw[L] : dvv[L] + cross(dw[L], rA));
+      if (L == lb) dvp = dvp - (ang ? dw[L] : dvv[L] + cross(dw[L], rB));
+      PIH_MEM_FENCE();
     }
+#pragma unroll
+    for (int L = 0; L < ANL; L++) out.wa[L] = wq[L];
   }
   if (obj && out.wp) {
+    // The link constants of step j + 1 (joint axis, 1/D, U, r: 13 words, addresses fixed at compile time) are requested at the top of
+    // step j, the impulse terms of linkA / linkB are formed once before the sweeps, and the 29 results are stored after them: as
+    // written before -- every LDS read right in front of its use, a read of LO inside each `if (L == la)`, a store through the generic
+    // pointer wp in every step (which no later LDS read may be moved across) -- a step was three or four serialised LDS round trips.
+    const bool pa = la >= ANL, pb = lb >= ANL;
+    const V3 rA = p - ld3(sh.LO[pa ? la : ANL]), rB = p - ld3(sh.LO[pb ? lb : ANL]);
+    const V3 tqa = ang ? dir : cross(rA, dir), tqb = ang ? dir : cross(rB, dir), tl = ang ? mk(0, 0, 0) : dir;
+    struct LinkC { V3 a, Ua, Ul, r; real Di; };
+    auto linkc = [&](int L) __attribute__((always_inline)) -> LinkC {
+      LinkC c; c.a = ld3(sh.LA[L]); c.Ua = ld3(sh.AU[L]); c.Ul = ld3(sh.AU[L] + 3); c.r = ld3(sh.AR[L]); c.Di = sh.ADinv[L]; return c;
+    };
     V3 Qa = mk(0, 0, 0), Ql = mk(0, 0, 0); real uu[ONL];
+    LinkC nx = linkc(NL - 1);
 #pragma unroll
     for (int j = ONL - 1; j >= 0; j--) {
       const int L = ANL + j;
-      if (L == la) { Qa = Qa + (ang ? dir : cross(p - ld3(sh.LO[L]), dir)); Ql = Ql + (ang ? mk(0, 0, 0) : dir); }
-      if (L == lb) { Qa = Qa - (ang ? dir : cross(p - ld3(sh.LO[L]), dir)); Ql = Ql - (ang ? mk(0, 0, 0) : dir); }
+      const LinkC c = nx;
+      if (j > 1) nx = linkc(L - 1);
+      if (L == la) { Qa = Qa + tqa; Ql = Ql + tl; }
+      if (L == lb) { Qa = Qa - tqb; Ql = Ql - tl; }
       if (j > 0) {
-        V3 a = ld3(sh.LA[L]);
-        real u = (L == jm ? (real)1 : (real)0) + dot(a, Qa);
+        real u = (L == jm ? (real)1 : (real)0) + dot(c.a, Qa);
         uu[j] = u;
-        real ud = u * sh.ADinv[L];
-        V3 qa = Qa - ud * ld3(sh.AU[L]), ql = Ql - ud * ld3(sh.AU[L] + 3);
-        Qa = qa + cross(ld3(sh.AR[L]), ql); Ql = ql;
+        real ud = u * c.Di;
+        V3 qa = Qa - ud * c.Ua, ql = Ql - ud * c.Ul;
+        Qa = qa + cross(c.r, ql); Ql = ql;
       }
+      PIH_MEM_FENCE();      // one link ahead, not all 24: without this every prefetch is hoisted to the top and spilled
     }
     // root: (alpha, v) = Inv6 * Q
     real Q[6] = {Qa.x, Qa.y, Qa.z, Ql.x, Ql.y, Ql.z}, x[6];
@@ -761,20 +793,27 @@ PIH_HD real response(const Shared& sh, int la, int lb, V3 p, V3 dir, int jm, Row
       for (int k = 0; k < 6; k++) s += sh.Inv6[6 * i + k] * Q[k];
       x[i] = s; }
     V3 dw = mk(x[0], x[1], x[2]), dvv = mk(x[3], x[4], x[5]);
-    out.wp[0] = dvv.x; out.wp[1] = dvv.y; out.wp[2] = dvv.z; out.wp[3] = dw.x; out.wp[4] = dw.y; out.wp[5] = dw.z;
-    if (ANL == la) dvp = dvp + (ang ? dw : dvv + cross(dw, p - ld3(sh.LO[ANL])));
-    if (ANL == lb) dvp = dvp - (ang ? dw : dvv + cross(dw, p - ld3(sh.LO[ANL])));
+    real wq[5 + ONL];
+    wq[0] = dvv.x; wq[1] = dvv.y; wq[2] = dvv.z; wq[3] = dw.x; wq[4] = dw.y; wq[5] = dw.z;
+    if (ANL == la) dvp = dvp + (ang ? dw : dvv + cross(dw, rA));
+    if (ANL == lb) dvp = dvp - (ang ? dw : dvv + cross(dw, rB));
+    nx = linkc(ANL + 1);
 #pragma unroll
     for (int j = 1; j < ONL; j++) {
       const int L = ANL + j;
-      V3 ll = dvv + cross(dw, ld3(sh.AR[L]));
-      real dq = (uu[j] - dot(ld3(sh.AU[L]), dw) - dot(ld3(sh.AU[L] + 3), ll)) * sh.ADinv[L];
-      dw = dw + dq * ld3(sh.LA[L]); dvv = ll;
-      out.wp[5 + j] = dq;
+      const LinkC c = nx;
+      if (j + 1 < ONL) nx = linkc(L + 1);
+      V3 ll = dvv + cross(dw, c.r);
+      real dq = (uu[j] - dot(c.Ua, dw) - dot(c.Ul, ll)) * c.Di;
+      dw = dw + dq * c.a; dvv = ll;
+      wq[5 + j] = dq;
       if (L == jm) jw += dq;
-      if (L == la) dvp = dvp + (ang ? dw : dvv + cross(dw, p - ld3(sh.LO[L])));
-      if (L == lb) dvp = dvp - (ang ? dw : dvv + cross(dw, p - ld3(sh.LO[L])));
+      if (L == la) dvp = dvp + (ang ? dw : dvv + cross(dw, rA));
+      if (L == lb) dvp = dvp - (ang ? dw : dvv + cross(dw, rB));
+      PIH_MEM_FENCE();
     }
+#pragma unroll
+    for (int k = 0; k < 5 + ONL; k++) out.wp[k] = wq[k];
   }
   if (dvp_out) *dvp_out = dvp;   // relative velocity change at the contact point per unit impulse along dir
   return jw + dot(dir, dvp);
