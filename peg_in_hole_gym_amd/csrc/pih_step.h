@@ -50,16 +50,20 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
   // pipe links follow.
   {
     struct Acc { V3 al, ac; };
-    auto olink = [&](int L, const Acc& par) __attribute__((always_inline)) -> Acc {
+    // link constants (r, c, U, u, 1/D, axis: 18 words), requested one step ahead of their use: the store of qdd below is an LDS write
+    // that no later LDS read may be moved across
+    struct OC { V3 r, ca, cl, Ua, Ul, a; real u, Di; };
+    auto oconst = [&](int L) __attribute__((always_inline)) -> OC {
+      OC c; c.r = ld3(sh.AR[L]); c.ca = ld3(sh.a.CB[L]); c.cl = ld3(sh.a.CB[L] + 3); c.Ua = ld3(sh.AU[L]); c.Ul = ld3(sh.AU[L] + 3);
+      c.a = ld3(sh.LA[L]); c.u = sh.Au[L]; c.Di = sh.ADinv[L]; return c;
+    };
+    auto olink = [&](int L, const Acc& par, const OC& c) __attribute__((always_inline)) -> Acc {
       const int jt = L_JTYPE[L], d = link_dof(L);
-      V3 r = ld3(sh.AR[L]);
-      V3 aa = par.al + ld3(sh.a.CB[L]);
-      V3 ll = par.ac + cross(par.al, r) + ld3(sh.a.CB[L] + 3);
-      V3 Ua = ld3(sh.AU[L]), Ul = ld3(sh.AU[L] + 3);
-      real qdd = (sh.Au[L] - dot(Ua, aa) - dot(Ul, ll)) * sh.ADinv[L];
-      V3 a = ld3(sh.LA[L]);
+      V3 aa = par.al + c.ca;
+      V3 ll = par.ac + cross(par.al, c.r) + c.cl;
+      real qdd = (c.u - dot(c.Ua, aa) - dot(c.Ul, ll)) * c.Di;
       Acc o;
-      if (jt == PIH_JT_REVOLUTE) { o.al = aa + qdd * a; o.ac = ll; } else { o.al = aa; o.ac = ll + qdd * a; }
+      if (jt == PIH_JT_REVOLUTE) { o.al = aa + qdd * c.a; o.ac = ll; } else { o.al = aa; o.ac = ll + qdd * c.a; }
       sh.udot[d] = qdd;
       return o;
     };
@@ -72,13 +76,21 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
       sh.udot[d] = pipe.ac.x; sh.udot[d + 1] = pipe.ac.y; sh.udot[d + 2] = pipe.ac.z; sh.udot[d + 3] = pipe.al.x; sh.udot[d + 4] = pipe.al.y; sh.udot[d + 5] = pipe.al.z;
     }
     arm.al = mk(0, 0, 0); arm.ac = mk(0, 0, 0); arm6 = arm;            // the arm's parent is the fixed world
+    OC na_c = oconst(0), np_c = oconst(ANL + 1);
     for (int k = 0; k < ANL; k++) {
+      const OC ca = na_c, cp = np_c;
+      if (k + 1 < ANL) na_c = oconst(k + 1);
+      np_c = oconst(ANL + 2 + k);                                      // (k = 8: link 19, the first of the unpaired tail)
       const Acc pa = k == ANL - 1 ? arm6 : arm;                        // the second finger hangs on link 6 like the first
-      const Acc na = olink(k, pa), np = olink(ANL + 1 + k, pipe);
+      const Acc na = olink(k, pa, ca), np = olink(ANL + 1 + k, pipe, cp);
       arm = na; pipe = np;
       if (k == ANL - 3) arm6 = na;
     }
-    for (int L = 2 * ANL + 1; L < NL; L++) pipe = olink(L, pipe);
+    for (int L = 2 * ANL + 1; L < NL; L++) {
+      const OC c = np_c;
+      if (L + 1 < NL) np_c = oconst(L + 1);
+      pipe = olink(L, pipe, c);
+    }
   }
 }
 
