@@ -348,9 +348,11 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
     int la = -1, lb = -1; V3 p = mk(0, 0, 0), dir = mk(0, 0, 0); bool ang = false;
     if (live) { la = sh.c_la[c]; lb = sh.c_lb[c]; const real* R = sh.b.crec[c]; p = ld3(R); dir = ld3(R + 8 + 4 * k); ang = R[6] != 0; }
     const int md = lane < 9 ? lane : 15 + (lane - 9);
+    DofGeom gn = dof_geom(sh, 0);
 #pragma unroll
     for (int d = 0; d < ND; d++) {
-      const DofGeom g = dof_geom(sh, d);
+      const DofGeom g = gn;
+      if (d + 1 < ND) gn = dof_geom(sh, d + 1);           // the next DOF's axis / origin are in flight while this entry is computed
       const real jc = live ? jac_entry(g, la, lb, p, dir, ang) : (real)0;
       J[d] = ismotor ? (d == md ? (real)1 : (real)0) : jc;
       __asm__ volatile("" : "+v"(J[d]) :: "memory");     // one DOF at a time (same reason as for the columns of A below)
@@ -378,14 +380,13 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
 #pragma unroll
   for (int c = 0; c < MERGED_CONTACTS; c++) {
     if (c < nc) {
+      // (the three response rows of a contact are requested together: one LDS round trip per contact instead of one per column)
+      real a0 = 0, a1 = 0, a2 = 0;
+      const real* wr = sh.b.Wp[3 * c];
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const real* wr = sh.b.Wp[3 * c + k]; real a = 0;
-#pragma unroll
-        for (int d = 0; d < ND; d++) a += J[d] * wr[d];
-        __asm__ volatile("" : "+v"(a) :: "memory");
-        A[NMOT + 3 * c + k] = a;
-      }
+      for (int d = 0; d < ND; d++) { a0 += J[d] * wr[d]; a1 += J[d] * wr[WPS + d]; a2 += J[d] * wr[2 * WPS + d]; }
+      __asm__ volatile("" : "+v"(a0), "+v"(a1), "+v"(a2) :: "memory");
+      A[NMOT + 3 * c] = a0; A[NMOT + 3 * c + 1] = a1; A[NMOT + 3 * c + 2] = a2;
     } else { A[NMOT + 3 * c] = 0; A[NMOT + 3 * c + 1] = 0; A[NMOT + 3 * c + 2] = 0; }
   }
   // ---- per-lane row constants.  The solve runs on z = lambda + rhs - dinv (J du) of the lane's own row ("the multiplier the row
@@ -664,9 +665,11 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
     int la0, lb0, la1, lb1; V3 p0, d0, p1, d1; bool a0, a1, l0, l1;
     geom(lane, la0, lb0, p0, d0, a0, l0); geom(64 + lane, la1, lb1, p1, d1, a1, l1);
     const int md = lane < 9 ? lane : 15 + (lane - 9);
+    DofGeom gn = dof_geom(sh, 0);
 #pragma unroll
     for (int d = 0; d < ND; d++) {
-      const DofGeom g = dof_geom(sh, d);
+      const DofGeom g = gn;
+      if (d + 1 < ND) gn = dof_geom(sh, d + 1);
       J0[d] = lane < NMOT ? (d == md ? (real)1 : (real)0) : (l0 ? jac_entry(g, la0, lb0, p0, d0, a0) : (real)0);
       J1[d] = l1 ? jac_entry(g, la1, lb1, p1, d1, a1) : (real)0;
       __asm__ volatile("" : "+v"(J0[d]), "+v"(J1[d]) :: "memory");
@@ -677,13 +680,18 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
 #pragma unroll 1
   for (int cb = 0; cb < HC; cb++) {                          // (rolled: the register-resident columns are handled by the switch below)
     if (cb >= nc) break;
+    // the three response rows of the contact are requested together (they are contiguous, LDS or scratch): one round trip per contact
+    const real* wr = wp_row(sh, ov, 3 * cb);
+    real a0[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) { const real wv = wr[k * WPS + d]; a0[k] += J0[d] * wv; a1[k] += J1[d] * wv; }
+    }
+#pragma unroll
     for (int k = 0; k < 3; k++) {
       const int i = NMOT + 3 * cb + k;
-      const real* wr = wp_row(sh, ov, 3 * cb + k);
-      real a0 = 0, a1 = 0;
-#pragma unroll
-      for (int d = 0; d < ND; d++) { const real wv = wr[d]; a0 += J0[d] * wv; a1 += J1[d] * wv; }
-      const real b0 = (lane == i ? (real)1 : (real)0) - c0.di * a0, b1 = (64 + lane == i ? (real)1 : (real)0) - c1.di * a1;
+      const real b0 = (lane == i ? (real)1 : (real)0) - c0.di * a0[k], b1 = (64 + lane == i ? (real)1 : (real)0) - c1.di * a1[k];
       if (i >= KREG) { Bg[(size_t)(i - KREG) * 128] = b0; Bg[(size_t)(i - KREG) * 128 + 1] = b1; }
       else {
         // register-resident column: static index through a fully unrolled select (i is wave-uniform)
