@@ -641,9 +641,10 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       }
       if (w0) a0 = w0[dm];
       const real a1 = w1 ? w1[dm] : (real)0;
+      // (no pin between the 32 columns: the 64 reads -- LDS, or the scratch in global memory for rows of contacts >= CL -- target the
+      //  registers that stay, and all are in flight together instead of 32 serialised round trips)
       B0[m] = ((lane == m && m >= 9) ? (real)1 : (real)0) - c0.di * a0;
       B1[m] = -c1.di * a1;
-      __asm__ volatile("" : "+v"(B0[m]), "+v"(B1[m]) :: "memory");
     }
   }
   // the motor rows' registers are not needed again before the very end: park them in the env's scratch
