@@ -59,6 +59,17 @@ struct Wave {
 // ------------------------------------------------------------------------------------------------ cross-lane helpers
 // x[g] = y[g] for ONE lane g known at compile time.  The lane mask is made on the spot by the scalar unit (s_lshl_b64 of inline
 // constants): as a 64-bit constant operand it would be hoisted out of the solver loop, one SGPR pair per row, and spilled.
+// two floats in one 64-bit VGPR pair and z += b * s on both halves in ONE instruction (v_pk_fma_f32, s a wave-uniform scalar).  Written
+// as asm on an integer container on purpose: with float2 vector types this toolchain emits the packed FMA but then reads the wrong
+// half of the pair in a following v_readlane (checked on the MI355X); the integer form extracts sub-registers correctly.
+typedef unsigned long long pk2;
+PIH_HD pk2 pk_pack(real x, real y) { return (pk2)__builtin_bit_cast(unsigned, x) | ((pk2)__builtin_bit_cast(unsigned, y) << 32); }
+PIH_HD real pk_lo(pk2 v) { return __builtin_bit_cast(float, (unsigned)v); }
+PIH_HD real pk_hi(pk2 v) { return __builtin_bit_cast(float, (unsigned)(v >> 32)); }
+PIH_HD void pk_fma(pk2& z, pk2 b, real s) {
+  const pk2 s64 = (pk2)__builtin_bit_cast(unsigned, s);
+  __asm__("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[0,1,1]" : "+v"(z) : "v"(b), "s"(s64));
+}
 PIH_HD void commit_lane(real& x, real y, int g) {
   unsigned long long m;
   __asm__ volatile("s_lshl_b64 %1, 1, %3\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(x), "=&s"(m) : "v"(y), "n"(g) : "scc");   // s_lshl_b64 writes SCC
@@ -623,7 +634,7 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
   };
   const RowC c0 = rowconst(lane), c1 = rowconst(64 + lane);
   // ---- columns.  Bn[i] = [own row] - dinv A[i]
-  real B0[KREG], B1[KREG];
+  pk2 BB[KREG];                                            // (row of register set 0, row of register set 1) per column
   // motor columns by symmetry: A[r][m] = W_r[dof(m)].  Contact rows read their own response row; motor rows take the (lane = DOF)
   // registers of the motor rows: arm lane r holds W_m[r] itself, pipe lane r finds W_m[dof(r)] six lanes up
   {
@@ -643,8 +654,7 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       const real a1 = w1 ? w1[dm] : (real)0;
       // (no pin between the 32 columns: the 64 reads -- LDS, or the scratch in global memory for rows of contacts >= CL -- target the
       //  registers that stay, and all are in flight together instead of 32 serialised round trips)
-      B0[m] = ((lane == m && m >= 9) ? (real)1 : (real)0) - c0.di * a0;
-      B1[m] = -c1.di * a1;
+      BB[m] = pk_pack(((lane == m && m >= 9) ? (real)1 : (real)0) - c0.di * a0, -c1.di * a1);
     }
   }
   // the motor rows' registers are not needed again before the very end: park them in the env's scratch
@@ -697,12 +707,12 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       else {
         // register-resident column: static index through a fully unrolled select (i is wave-uniform)
 #pragma unroll
-        for (int q = NMOT; q < KREG; q++) if (q == i) { B0[q] = b0; B1[q] = b1; }
+        for (int q = NMOT; q < KREG; q++) if (q == i) BB[q] = pk_pack(b0, b1);
       }
     }
   }
 #pragma unroll
-  for (int q = NMOT; q < KREG; q++) if (q >= NMOT + 3 * nc) { B0[q] = 0; B1[q] = 0; }
+  for (int q = NMOT; q < KREG; q++) if (q >= NMOT + 3 * nc) BB[q] = 0;
   unsigned angmask = 0;
   for (int c = 0; c < nc; c++) { const real* R = c < CL ? sh.b.crec[c] : ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC; if (R[5] < 0) angmask |= 1u << c; }
   angmask = (unsigned)__builtin_amdgcn_readfirstlane((int)angmask);
@@ -720,7 +730,7 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       if (i >= KREG) { b0 = Bg[(size_t)(i - KREG) * 128]; b1 = Bg[(size_t)(i - KREG) * 128 + 1]; }
       else { b0 = 0; b1 = 0;
 #pragma unroll
-        for (int q = NMOT; q < KREG; q += 3) if (q == i) { b0 = B0[q]; b1 = B1[q]; } }
+        for (int q = NMOT; q < KREG; q += 3) if (q == i) { b0 = pk_lo(BB[q]); b1 = pk_hi(BB[q]); } }
       v0 += b0 * l; v1 += b1 * l;
     }
     z0 = c0.rhs + v0; z1 = c1.rhs + v1;
@@ -733,14 +743,14 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
     // ring of streamed columns: the first D are requested before the motor rows
     int l8 = lane * 8;
     __asm__ volatile("" : "+v"(l8));                       // (opaque once per iteration: the "+ 4" of the second word stays an immediate offset)
-    real r0[D], r1[D];
+    pk2 rr[D];
 #pragma unroll
-    for (int s = 0; s < D; s++) { const F2 t = ldcol(s, l8); r0[s] = t.x; r1[s] = t.y; }
+    for (int s = 0; s < D; s++) { const F2 t = ldcol(s, l8); rr[s] = pk_pack(t.x, t.y); }
     constexpr int PF = 2;
     real4 pa4[PF], pl4[PF];
 #pragma unroll
     for (int k = 0; k < PF; k++) { pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
-    real za = z0, zp = z0;
+    real za = z0; pk2 zp1 = pk_pack(z0, z1);               // arm chain; (pipe chain, register set 1)
 #pragma unroll
     for (int j = 0; j < PIH_OBJ_NJ; j++) {
       if (j < 9) {
@@ -763,26 +773,26 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
         const real d3 = s3 - lh; commit(lamhi, s3, j);
         if (CHECK) busy |= __ballot(absr(d3) > th);
         const real tot = dl + d2 - d3;
-        za += B0[j] * tot; z1 += B1[j] * tot;
+        za += pk_lo(BB[j]) * tot; zp1 = pk_pack(pk_lo(zp1), pk_hi(zp1) + pk_hi(BB[j]) * tot);
       }
       const int g = 9 + j;
-      const real cand = med3_(zp, c0.lb, c0.ub);
+      const real cand = med3_(pk_lo(zp1), c0.lb, c0.ub);
       const real dlv = cand - lam0;
       const real sdl = rdlane(dlv, g);
       if (CHECK) busy |= __ballot(absr(dlv) > c0.thr) & (1ull << g);
       commit(lam0, cand, g);
-      zp += B0[g] * sdl; z1 += B1[g] * sdl;
+      pk_fma(zp1, BB[g], sdl);
     }
-    z0 = (za + zp) - z0;
+    pk2 zz = pk_pack((za + pk_lo(zp1)) - z0, pk_hi(zp1));
     // one row: clamp the lane's own z, take the row's step from its lane, move every z
-    auto rowstep = [&](int g, real lo0, real hi0, real lo1, real hi1, real b0, real b1) __attribute__((always_inline)) -> real {
+    auto rowstep = [&](int g, real lo0, real hi0, real lo1, real hi1, pk2 bb) __attribute__((always_inline)) -> real {
       real cand, dlv;
-      if (g < 64) { cand = med3_(z0, lo0, hi0); dlv = cand - lam0; if (CHECK) busy |= __ballot(absr(dlv) > c0.thr) & (1ull << g); }
-      else { cand = med3_(z1, lo1, hi1); dlv = cand - lam1; if (CHECK) busy |= __ballot(absr(dlv) > c1.thr) & (1ull << (g - 64)); }
+      if (g < 64) { cand = med3_(pk_lo(zz), lo0, hi0); dlv = cand - lam0; if (CHECK) busy |= __ballot(absr(dlv) > c0.thr) & (1ull << g); }
+      else { cand = med3_(pk_hi(zz), lo1, hi1); dlv = cand - lam1; if (CHECK) busy |= __ballot(absr(dlv) > c1.thr) & (1ull << (g - 64)); }
       const real sdl = rdlane(dlv, g & 63);
       const real sc = rdlane(cand, g & 63);
       if (g < 64) commit(lam0, cand, g); else commit(lam1, cand, g - 64);
-      z0 += b0 * sdl; z1 += b1 * sdl;
+      pk_fma(zz, bb, sdl);
       return sc;
     };
 #pragma unroll
@@ -793,26 +803,27 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       __asm__ volatile("" : "+s"(ncl), "+s"(am));
       if (c >= ncl) break;
       const int g0 = NMOT + 3 * c;
-      real b0[3], b1[3];
+      pk2 bb[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const int i = g0 + k;
-        if (i < KREG) { b0[k] = B0[i < KREG ? i : 0]; b1[k] = B1[i < KREG ? i : 0]; }
+        if (i < KREG) bb[k] = BB[i < KREG ? i : 0];
         else {
           const int s = i - KREG;
-          b0[k] = r0[s % D]; b1[k] = r1[s % D];
+          bb[k] = rr[s % D];
           const F2 t = ldcol(s + D, l8);                    // request the column a ring ahead (clamped: a harmless reload at the end)
-          r0[s % D] = t.x; r1[s % D] = t.y;
+          rr[s % D] = pk_pack(t.x, t.y);
         }
       }
-      const real s0 = rowstep(g0, c0.lb, c0.ub, c1.lb, c1.ub, b0[0], b1[0]);
+      const real s0 = rowstep(g0, c0.lb, c0.ub, c1.lb, c1.ub, bb[0]);
       const bool loaded = s0 > 0 || ((am >> c) & 1u);
       if (loaded) {                                        // wave-uniform (Bullet leaves the friction rows of an unloaded contact alone)
         const real h0 = max_(c0.mu * s0, c0.fl), h1 = max_(c1.mu * s0, c1.fl);
-        rowstep(g0 + 1, -h0, h0, -h1, h1, b0[1], b1[1]);
-        rowstep(g0 + 2, -h0, h0, -h1, h1, b0[2], b1[2]);
+        rowstep(g0 + 1, -h0, h0, -h1, h1, bb[1]);
+        rowstep(g0 + 2, -h0, h0, -h1, h1, bb[2]);
       }
     }
+    z0 = pk_lo(zz); z1 = pk_hi(zz);
     return CHECK && busy == 0;
   };
   const int it = pgs_iteration_loop<false>(P.iters, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
