@@ -622,10 +622,12 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
     w.par_all(253, [&](int idx, bool in) {
       bool valid = false; V3 n = mk(0, 0, 0), p = mk(0, 0, 0); real depth = 0; int s = 0, t = 0;
       if (in) {
-        // idx -> (s,t): row s has (22 - s) entries (t = s+2..23)
-        int rem = idx; s = 0;
-        while (rem >= 22 - s) { rem -= 22 - s; s++; }
-        t = s + 2 + rem;
+        // idx -> (s,t): row s has (22 - s) entries (t = s+2..23), C(s) = s (45 - s) / 2 pairs come before it: closed form + one
+        // correction step either way instead of a per-lane search loop of up to 22 trips (the whole wave waited for the longest)
+        s = (int)((real)0.5 * ((real)45 - (real)sqrt((real)(2025 - 8 * idx))));
+        if ((s + 1) * (44 - s) / 2 <= idx) s++;
+        if (s * (45 - s) / 2 > idx) s--;
+        t = s + 2 + idx - s * (45 - s) / 2;
         // vertex v = first sample of segment v (v<24) / last sample (v=24): sample index of vertex v
         auto vtx = [&](int v) -> V3 { int si = v == 0 ? 0 : (v == 24 ? NSAMP - 1 : 7 + 5 * (v - 1)); return ld3(sh.a.SP[si]); };
         V3 p1 = vtx(s), q1 = vtx(s + 1), p2 = vtx(t), q2 = vtx(t + 1);
