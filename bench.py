@@ -16,7 +16,9 @@ block-partitioned, the stacked observation all-gathered over RCCL each step (SUR
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = 828 algorithmic bytes per env-step x envs per launch
 / average pih_step_kernel duration measured with HIP events on the launch stream (pih_timing2; the controller/sort
-pre-kernel is reported next to it).  `cpu_baseline` = the CPU restatement in oracle/ ("port": NOT PyBullet, which is not
+pre-kernel is reported next to it).  The events bracket every 4th step launch of the timed region (--timing-stride): three
+hipEventRecord per step drain the queue between the two kernels of a step (+30 us on a 430 us step, measured), which would
+otherwise be charged to the throughput being measured; `roofline.launches` is the number of launches that carried events.  `cpu_baseline` = the CPU restatement in oracle/ ("port": NOT PyBullet, which is not
 installable here) built -O3 -march=native on this box and timed on its host cores on a bounded, pre-rolled sample.
 """
 import argparse
@@ -223,6 +225,7 @@ def main():
     ap.add_argument("--task", default="peg-in-hole", choices=["peg-in-hole", "random-fly"], help="random-fly = BASELINE configs[4]: UR5 + free-flying object, args=['Banana', 1/120.]")
     ap.add_argument("--mode", default="action", choices=["action", "scripted"], help="action = panda_execute per step (headline); scripted = the reference's grasp-and-insert state machine")
     ap.add_argument("--solver-path", type=int, default=0, help="1 = DOF-space PGS for every env (A/B against the default row-space path for <= 10 contacts)")
+    ap.add_argument("--timing-stride", type=int, default=4, help="HIP events bracket every k-th step launch of the timed region (3 event records per step cost ~30 us of queue drain on a 430 us step; k = 1: every launch)")
     ap.add_argument("--schedule", type=int, default=1, help="dispatch order: 1 longest-job-first (default), 0 env order, 2 partner-aware (experimental); +4: no wave priority for heavy envs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (1-GPU box, gloo backend)")
@@ -299,7 +302,7 @@ def main():
     sync()
     c_start = contacts()
     if env is not None:
-        env.set_timing(True)
+        env.set_timing(args.timing_stride)
         env.timing2(reset=True)
     if dist is not None:
         dist.barrier()
@@ -359,7 +362,7 @@ def main():
                        "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + %s all-gather(obs)" % ("RCCL" if args.backend == "nccl" and use_gpu else "gloo"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (alg_bytes * n),
-                         "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel", "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches,
+                         "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel", "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches, "event_stride": args.timing_stride,
                          "alg_bytes_per_env_step": alg_bytes, "note": note},
             "sanity": {"state_finite": finite, "mean_contacts": 0.5 * (c_start + c_end), "mean_contacts_start": c_start, "mean_contacts_end": c_end,
                        "pgs_variant_share": variants,

@@ -164,6 +164,9 @@ int pih_grasp_labels(pih_handle* h, float* out_dev, float* meta_dev, int size, i
  * reset=1; pih_timing2 also splits it into the controller/sort launch and the physics launch */
 int pih_timing(pih_handle* h, int reset, double* avg_ms_out, int64_t* launches_out);
 int pih_timing2(pih_handle* h, int reset, double* pre_ms_out, double* step_ms_out, int64_t* launches_out);
+/* enable = 0: off; 1: every step launch is bracketed by events; k > 1: every k-th launch only.  (Three hipEventRecord per step drain
+ * the queue between the two kernels of a step: +30 us on a 430 us step measured on the MI355X -- a throughput measurement that also
+ * wants kernel times samples them.) */
 int pih_set_timing(pih_handle* h, int enable);
 const char* pih_last_error(pih_handle* h);
 

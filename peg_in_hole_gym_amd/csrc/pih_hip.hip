@@ -291,7 +291,8 @@ struct pih_handle {
   float* ovf = nullptr;     // spill area for contacts beyond the LDS-resident CL (rarely touched)
   int* order = nullptr;     // longest-job-first block -> env map (block 0 of pih_pre_kernel)
   std::string err;
-  bool timing = false;
+  int timing = 0;           // 0 off; k >= 1: every k-th step launch is bracketed by events (pih_set_timing)
+  unsigned timing_tick = 0;
   std::vector<EvTriple> ev;   // (before pre-kernel, between, after step kernel) of each timed step launch
   size_t ev_used = 0;
   double acc_pre_ms = 0, acc_step_ms = 0; int64_t acc_n = 0;
@@ -442,7 +443,7 @@ int pih_reseed(pih_handle* h, uint64_t seed) {
 
 static int launch_step(pih_handle* h, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t s) {
   EvTriple* t = nullptr;
-  if (h->timing) {
+  if (h->timing > 0 && (h->timing_tick++ % (unsigned)h->timing) == 0) {
     if (h->ev_used == EV_POOL) { int r = drain_events(h); if (r) return r; }
     if (h->ev_used == h->ev.size()) {
       EvTriple n;
@@ -583,7 +584,7 @@ int pih_grasp_labels(pih_handle* h, float* out_dev, float* meta_dev, int size, i
   return 0;
 }
 
-int pih_set_timing(pih_handle* h, int enable) { if (!h) return -2; h->timing = enable != 0; return 0; }
+int pih_set_timing(pih_handle* h, int enable) { if (!h) return -2; h->timing = enable > 0 ? enable : 0; h->timing_tick = 0; return 0; }
 
 int pih_timing2(pih_handle* h, int reset, double* pre_ms_out, double* step_ms_out, int64_t* launches_out) {
   if (!h) return -2;
