@@ -49,18 +49,44 @@ def counted_flops():
         return None
 
 
-def pmc_traffic(n_envs):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/pmc_latest.json, produced by
-    tools/pmc_traffic.sh in separate --pmc passes): counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+def _source_sha16():
     try:
-        d = json.load(open(path))
+        from tools.source_hash import source_sha16
+        return source_sha16()
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def pmc_traffic(n_envs, fly=False):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/pmc[_fly]_latest.json, produced by
+    tools/pmc_traffic.sh in separate --pmc passes): counters cannot be read from inside this process.  The summary carries the hash
+    of the kernel sources it was measured on; `stale` = the sources have changed since (re-profile before quoting the figure)."""
+    name = "pmc_fly_latest.json" if fly else "pmc_latest.json"
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
         if d.get("n_envs") == n_envs and d.get("traffic_raw"):
             return d["traffic_raw"], {"fetch_size_kib": d["fetch_size_kib"], "write_size_kib": d["write_size_kib"],
-                                      "fetch_x2_variant": d["traffic_fetch_x2"], "source": "profiles/pmc_latest.json (%s)" % d.get("tag")}
+                                      "fetch_x2_variant": d["traffic_fetch_x2"], "source": "profiles/%s (%s)" % (name, d.get("tag")),
+                                      "measured_on_source_sha16": d.get("source_sha16"), "stale": d.get("source_sha16") != _source_sha16()}
     except Exception:  # noqa: BLE001
         pass
     return None, None
+
+
+def valu_issue(fly=False):
+    """The bound this path is actually up against (not HBM, not MFMA): VALU issue slots.  From the committed SQ-counter
+    summary (profiles/sq[_fly]_latest.json, tools/pmc_sq.sh): per wave SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x resident waves per SIMD =
+    fraction of the SIMD's VALU issue slots in use while the kernel runs."""
+    name = "sq_fly_latest.json" if fly else "sq_latest.json"
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        per_wave = d["frac_SQ_ACTIVE_INST_VALU"]; waves = d.get("waves_per_simd", 2)
+        return {"frac_valu_issue": per_wave * waves, "valu_active_per_wave": per_wave, "waves_per_simd": waves,
+                "wait_any_per_wave": d.get("frac_SQ_WAIT_ANY"), "valu_insts_per_env_step": d.get("valu_insts_per_env_step"),
+                "source": "profiles/%s (%s)" % (name, d.get("tag")), "measured_on_source_sha16": d.get("source_sha16"),
+                "stale": d.get("source_sha16") != _source_sha16()}
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def cpu_baseline(preroll=300, budget_s=25.0):
@@ -226,6 +252,7 @@ def main():
     ap.add_argument("--mode", default="action", choices=["action", "scripted"], help="action = panda_execute per step (headline); scripted = the reference's grasp-and-insert state machine")
     ap.add_argument("--solver-path", type=int, default=0, help="1 = DOF-space PGS for every env (A/B against the default row-space path for <= 10 contacts)")
     ap.add_argument("--timing-stride", type=int, default=4, help="HIP events bracket every k-th step launch of the timed region (3 event records per step cost ~30 us of queue drain on a 430 us step; k = 1: every launch)")
+    ap.add_argument("--exit-check-stride", type=int, default=0, help="cadence of the PGS early-exit test: 0 = library default (16), 1 = Bullet's (every iteration)")
     ap.add_argument("--schedule", type=int, default=1, help="dispatch order: 1 longest-job-first (default), 0 env order, 2 partner-aware (experimental); +4: no wave priority for heavy envs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (1-GPU box, gloo backend)")
@@ -280,10 +307,18 @@ def main():
             env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, seed=args.seed, task_id=1, dt=1.0 / 120.0, max_episode_steps=480, contact_margin=0.02)
         else:
             mode_kw = dict(mode=1, dv=0.05) if args.mode == "scripted" else {}
+            if args.exit_check_stride > 0:
+                mode_kw["exit_check_stride"] = args.exit_check_stride
             env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, max_episode_steps=2227, seed=args.seed, solver_path=args.solver_path, schedule=args.schedule, **mode_kw)
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         pool = min(args.steps + args.warmup + args.preroll, 1024)
         actions = torch.rand(pool, n, adim, device=dev, generator=gen) * 2 - 1       # resident in HBM before the timed region
+    solver_cfg = None
+    if env is not None:     # what the run actually used (the library defaults unless a flag says otherwise): bench.py states the exit cadence
+        c = env.cfg
+        solver_cfg = {"solver_iters": int(c.solver_iters), "residual_threshold": float(c.residual_threshold), "warmstart": float(c.warmstart),
+                      "exit_check_stride": int(c.exit_check_stride), "exit_check": "Bullet's cadence (every iteration)" if c.exit_check_stride <= 1 else
+                      "sampled: iterations 1..4, 4 + %d k and the last" % c.exit_check_stride, "solver_path": int(c.solver_path)}
     local_obs = torch.zeros(n, odim, device=dev)
     gathered = torch.empty(world * n, odim, device=dev) if world > 1 and not args.no_allgather else None
 
@@ -343,13 +378,17 @@ def main():
         total_envs = n * world
         value = total_envs * args.steps / elapsed if not args.dry_run else None
         achieved = alg_bytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, traffic_detail = pmc_traffic(n) if not fly else (None, None)
+        traffic, traffic_detail = pmc_traffic(n, fly)
+        vi = valu_issue(fly)
         fl = counted_flops() if not fly else None
-        note = "latency/VALU/LDS-bound path (SURVEY.md 0.6): HBM fraction is ~0 by construction"
-        if fl and kernel_ms > 0:
-            tf = fl["flop_per_env_step"] * n / (kernel_ms * 1e-3) / 1e12
-            note += "; counted %.0f fp32 flop per env-step (%s) -> %.2f TFLOP/s = %.2f%% of the fp32 vector peak" % (
-                fl["flop_per_env_step"], fl.get("source", "profiles/flops_latest.json"), tf, 100 * tf / FP32_VECTOR_PEAK_TFLOPS)
+        note = "latency/VALU-issue-bound path (SURVEY.md 0.6): HBM fraction is ~0 by construction; the second bound reported here is the fraction of the SIMDs' VALU issue slots in use"
+        flops = None
+        if fl and kernel_ms > 0 and env is not None:
+            from tools.flop_model import env_step_flops
+            tot, pg, other = env_step_flops(st[:, 106].cpu().numpy(), st[:, 107].cpu().numpy(), st[:, 114].cpu().numpy().astype(int), fl)
+            tf = tot * n / (kernel_ms * 1e-3) / 1e12
+            flops = {"flop_per_env_step": tot, "pgs_modelled": pg, "other_phases_counted": other, "tflops": tf, "frac_fp32_vector_peak": tf / FP32_VECTOR_PEAK_TFLOPS,
+                     "source": "tools/flop_model.py: PGS modelled on the formulation each env executed (state words 106 / 107 / 114 of this run's final step), other phases counted (profiles/flops_latest.json)"}
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
@@ -357,13 +396,13 @@ def main():
             "config": {"workload": ("UR5 + random-fly (args=['Banana', 1/120.]), %d parallel envs per GPU, random actions U(-1,1)^6 through ur_execute, dt=1/120, auto-reset, pre-rolled %d steps" % (n, args.preroll)) if fly else
                                    "Panda peg-in-hole, %d parallel envs per GPU, %s, dt=1/240, auto-reset, pre-rolled %d steps to contact steady state" % (
                            n, "random actions U(-1,1)" if args.mode == "action" else "scripted grasp-and-insert episodes", args.preroll),
-                       "task": args.task,
+                       "task": args.task, "solver": solver_cfg,
                        "envs_per_gpu": n, "total_envs": total_envs, "preroll": args.preroll,
                        "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + %s all-gather(obs)" % ("RCCL" if args.backend == "nccl" and use_gpu else "gloo"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (alg_bytes * n),
                          "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel", "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches, "event_stride": args.timing_stride,
-                         "alg_bytes_per_env_step": alg_bytes, "note": note},
+                         "alg_bytes_per_env_step": alg_bytes, "valu_issue": vi, "frac_valu_issue": vi["frac_valu_issue"] if vi else None, "flops": flops, "note": note},
             "sanity": {"state_finite": finite, "mean_contacts": 0.5 * (c_start + c_end), "mean_contacts_start": c_start, "mean_contacts_end": c_end,
                        "pgs_variant_share": variants,
                        ("mean_episode_step" if fly else "mean_pgs_iters"): mean_iters},

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIH_ABI_VERSION 3
+#define PIH_ABI_VERSION 4
 #define PIH_STATE_WORDS 256   /* float words per env record: [0,128) physical state, [128,256) warm-start contact cache */
 #define PIH_ACTION_DIM 4      /* envs/peg_in_hole.py:12 */
 #define PIH_OBS_DIM 5         /* envs/peg_in_hole.py:13: finger1, finger2, ee x, y, z */
@@ -107,6 +107,12 @@ typedef struct pih_config {
                                  PGS beyond; 1: DOF-space PGS for every env (A/B runs and tests; same row sequence, results equal to rounding) */
   int32_t attach_ball;        /* p7 attach (createConstraint, envs/peg_in_hole.py:99-104): 0 (default) = 6-row weld honouring childFrameOrientation,
                                  1 = 3-row ball joint between the grasp point and the grasp-target origin (round-1 behaviour) */
+  int32_t exit_check_stride;  /* cadence of the PGS early-exit test (Bullet: largest squared row residual <= residual_threshold, evaluated after
+                                 EVERY iteration).  1 = Bullet's cadence; s > 1 = the test runs in iterations 1..4, then in iterations 4 + s k and in
+                                 the last one (an env that meets the threshold between two tests runs at most s - 1 further iterations, each of
+                                 whose row updates is below the threshold).  Default 16; the oracle has the same switch, tests/test_gpu_defaults.py
+                                 bounds the difference against Bullet's cadence; bench.py reports the value it ran with */
+  int32_t reserved_i;
   uint64_t seed;
   float dt;                   /* 1/240 */
   float residual_threshold;   /* 1e-7 */
@@ -129,11 +135,16 @@ int pih_task_dims(int task_id, int32_t out[3]);
 /* offsets_host: HOST float[n_envs,3] (envs/base_env.py:35-55 placement) or NULL for zeros */
 int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** out);
 int pih_destroy(pih_handle* h);
-/* mask_dev: uint8[n] (nonzero = reset that env) or NULL = all.  hard != 0 (resetSimulation, envs/base_env.py:85-86): the env
- * also forgets its RNG draw counter and its non-finite-reset count, i.e. it replays the scene sequence of its seed from the start */
-int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, void* stream);
-/* new base seed for all later resets (env seed = seed + 1000 + global env index); combine with a hard reset to restart the
- * draw sequence.  The reference never seeds (envs/peg_in_hole.py:239-267 use the global `random`). */
+/* mask_dev: uint8[n] (nonzero = reset that env) or NULL = all.
+ * hard != 0 = resetSimulation + reload (envs/base_env.py:85-86, envs/peg_in_hole.py:227-274): like the reference, a hard reset draws a
+ *   NEW scene -- every env keeps advancing its own RNG draw sequence (the reference keeps drawing from the global `random`); it only also
+ *   clears the env's non-finite-reset count and invalid flag.
+ * seed != 0: explicit replay -- the handle's base seed becomes `seed` (env seed = seed + 1000 + global env index) and the envs reset by
+ *   this call restart their draw sequence from its beginning.  seed == 0: keep the seed and continue the sequence.
+ * (The reference never seeds: envs/peg_in_hole.py:239-267 use the global `random`.) */
+int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, uint64_t seed, void* stream);
+/* new base seed for all later resets; the envs reset by the NEXT pih_reset call restart their draw sequence from its beginning
+ * (same as passing `seed` to that call) */
 int pih_reseed(pih_handle* h, uint64_t seed);
 /* actions_dev float[n,4]; obs_dev float[n,5]; reward_dev float[n]; done_dev uint8[n]
  * (PIH_TASK_RANDOM_FLY: actions float[n,6], obs float[n,6]) */

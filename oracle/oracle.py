@@ -18,7 +18,7 @@ def _config_type(real):
     class _Config(C.Structure):
         _fields_ = [("n_envs", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32), ("ik_iters", C.c_int32),
                     ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("enable_self_collision", C.c_int32),
-                    ("env_index0", C.c_int32), ("attach_ball", C.c_int32), ("enable_arm_collision", C.c_int32), ("seed", C.c_uint64), ("dt", real), ("residual_threshold", real),
+                    ("env_index0", C.c_int32), ("attach_ball", C.c_int32), ("enable_arm_collision", C.c_int32), ("exit_check_stride", C.c_int32), ("reserved_i", C.c_int32), ("seed", C.c_uint64), ("dt", real), ("residual_threshold", real),
                     ("erp", real), ("warmstart", real), ("contact_margin", real), ("linear_slop", real),
                     ("ik_damping", real), ("ik_residual", real), ("dv", real)]
     return _Config
@@ -61,6 +61,12 @@ def lib(omp=False, path=None):
         L.piho_destroy.argtypes = [C.c_void_p]
         L.piho_reset.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         L.piho_reset_hard.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.piho_reset_ex.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_uint64]
+        L.piho_get_pgs_iters.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.piho_get_warm_cache.argtypes = [C.c_void_p, dp]
+        L.piho_get_pgs_residual.argtypes = [C.c_void_p, dp]
+        L.piho_set_warm_cache.argtypes = [C.c_void_p, dp]
+        L.piho_debug_contacts_all.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int32)]
         L.piho_reseed.argtypes = [C.c_void_p, C.c_uint64]
         L.piho_step.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_uint8)]
         for f in ("piho_get_state", "piho_get_tip_pose", "piho_get_contact_force"):
@@ -108,11 +114,12 @@ class Oracle:
             self.L.piho_destroy(self.h)
             self.h = None
 
-    def reset(self, mask=None, hard_reset=False):
+    def reset(self, mask=None, hard_reset=False, seed=0):
+        """same contract as pih_reset: hard = resetSimulation (a NEW scene like any reset); seed != 0 = explicit replay from that seed"""
         m = None
         if mask is not None:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
-        (self.L.piho_reset_hard if hard_reset else self.L.piho_reset)(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None)
+        self.L.piho_reset_ex(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None, int(bool(hard_reset)), int(seed))
 
     def reseed(self, seed):
         self.L.piho_reseed(self.h, int(seed))
@@ -138,10 +145,30 @@ class Oracle:
     def ncontacts(self):
         n = np.zeros(self.n, dtype=np.int32); self.L.piho_get_ncontacts(self.h, n.ctypes.data_as(C.POINTER(C.c_int32))); return n
 
+    def pgs_iters(self):
+        """PGS iterations executed in the last step (the product's state word PIH_S_PGS_ITERS)"""
+        n = np.zeros(self.n, dtype=np.int32); self.L.piho_get_pgs_iters(self.h, n.ctypes.data_as(C.POINTER(C.c_int32))); return n
+
+    def pgs_residual(self):
+        """largest squared row residual of the last PGS iteration executed in the last step (what Bullet compares with residual_threshold)"""
+        r = np.zeros(self.n, self.real); self.L.piho_get_pgs_residual(self.h, _dp(r)); return r
+
+    def warm_cache(self):
+        """warm-start contact cache in the layout of the product's state words 128..224: [n, 97] = count, 48 keys, 48 normal impulses"""
+        c = np.zeros((self.n, 97), self.real); self.L.piho_get_warm_cache(self.h, _dp(c)); return c
+
     def render(self, W=300, H=300, shaded=False):
         out = np.zeros((self.n, H, W, 4))
         self.L.piho_render_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         self.L.piho_render_ex(self.h, W, H, 1 if shaded else 0, _dp(out)); return out
+
+    def set_warm_cache(self, c):
+        c = np.ascontiguousarray(c, dtype=self.real).reshape(self.n, 97); self.L.piho_set_warm_cache(self.h, _dp(c))
+
+    def debug_contacts_all(self):
+        """contact lists of all envs from the last step: ([n, CMAX, 12] rows linkA linkB p n depth mu key lambda_n, counts [n])"""
+        out = np.zeros((self.n, CMAX, 12), self.real); cnt = np.zeros(self.n, dtype=np.int32)
+        self.L.piho_debug_contacts_all(self.h, _dp(out), cnt.ctypes.data_as(C.POINTER(C.c_int32))); return out, cnt
 
     def debug_contacts(self, env=0):
         out = np.zeros((CMAX, 12)); k = self.L.piho_debug_contacts(self.h, env, _dp(out)); return out[:k]
@@ -246,6 +273,8 @@ def _fly_protos(L):
     L.piho_fly_create.argtypes = [C.POINTER(L._cfg_type), dp]
     L.piho_fly_destroy.argtypes = [C.c_void_p]
     L.piho_fly_reset.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
+    L.piho_fly_reset_ex.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_uint64]
+    L.piho_fly_get_pgs_iters.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.piho_fly_step.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_uint8)]
     L.piho_fly_get_state.argtypes = [C.c_void_p, dp]
     L.piho_fly_set_state.argtypes = [C.c_void_p, dp]
@@ -276,9 +305,12 @@ class FlyOracle:
         if getattr(self, "h", None):
             self.L.piho_fly_destroy(self.h); self.h = None
 
-    def reset(self, mask=None, hard_reset=False):
+    def reset(self, mask=None, hard_reset=False, seed=0):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        self.L.piho_fly_reset(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None, int(hard_reset))
+        self.L.piho_fly_reset_ex(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None, int(hard_reset), int(seed))
+
+    def pgs_iters(self):
+        n = np.zeros(self.n, dtype=np.int32); self.L.piho_fly_get_pgs_iters(self.h, n.ctypes.data_as(C.POINTER(C.c_int32))); return n
 
     def step(self, actions):
         a = np.ascontiguousarray(actions, dtype=self.real).reshape(self.n, 6)
@@ -291,6 +323,14 @@ class FlyOracle:
 
     def set_state(self, s):
         s = np.ascontiguousarray(s, dtype=self.real).reshape(self.n, FLY_STATE_WORDS); self.L.piho_fly_set_state(self.h, _dp(s))
+
+    def set_warm_cache(self, c):
+        c = np.ascontiguousarray(c, dtype=self.real).reshape(self.n, 97); self.L.piho_set_warm_cache(self.h, _dp(c))
+
+    def debug_contacts_all(self):
+        """contact lists of all envs from the last step: ([n, CMAX, 12] rows linkA linkB p n depth mu key lambda_n, counts [n])"""
+        out = np.zeros((self.n, CMAX, 12), self.real); cnt = np.zeros(self.n, dtype=np.int32)
+        self.L.piho_debug_contacts_all(self.h, _dp(out), cnt.ctypes.data_as(C.POINTER(C.c_int32))); return out, cnt
 
     def debug_contacts(self, env=0):
         out = np.zeros((10, 10), self.real); self.L.piho_fly_debug_contacts(self.h, env, _dp(out)); return out

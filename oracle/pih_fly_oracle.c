@@ -46,6 +46,7 @@ typedef struct {
   real s[PIHO_FLY_STATE_WORDS];
   FContact contacts[FNC]; int ncontacts, landed;
   real contact_force, udot[FND];
+  int pgs_iters;
 } FEnv;
 struct piho_fly_handle { piho_config cfg; FEnv* env; };
 
@@ -280,8 +281,10 @@ static void fly_step_env(piho_fly_handle* h, int e, const real* action, real* ob
     r->rhs = (vb - ju) * r->dinv; r->lo = 0; r->hi = 1e30;
   }
   real dv[FND]; memset(dv, 0, sizeof dv);
+  E->pgs_iters = 0;
   for (int it = 0; it < c->solver_iters; it++) {
     real res2 = 0;
+    E->pgs_iters = it + 1;
     for (int i = 0; i < nr; i++) {
       FRow* r = &rows[i];
       real jd = 0; for (int k = 0; k < FND; k++) jd += r->J[k] * dv[k];
@@ -340,12 +343,16 @@ piho_fly_handle* piho_fly_create(const piho_config* c, const real* offsets) {
   return h;
 }
 void piho_fly_destroy(piho_fly_handle* h) { if (h) { free(h->env); free(h); } }
-void piho_fly_reset(piho_fly_handle* h, const uint8_t* mask, int hard) {
+void piho_fly_reset_ex(piho_fly_handle* h, const uint8_t* mask, int hard, uint64_t seed) {
+  if (seed != 0) h->cfg.seed = seed;
   for (int e = 0; e < h->cfg.n_envs; e++) if (!mask || mask[e]) {
-    if (hard) { h->env[e].s[PIHO_F_RNG] = 0; h->env[e].s[PIHO_F_RNG_HI] = 0; h->env[e].s[PIHO_F_SPARE] = 0; }
+    if (hard) h->env[e].s[PIHO_F_SPARE] = 0;                                            /* a new scene like any reset */
+    if (seed != 0) { h->env[e].s[PIHO_F_RNG] = 0; h->env[e].s[PIHO_F_RNG_HI] = 0; }     /* explicit replay */
     fly_reset_env(h, e);
   }
 }
+void piho_fly_reset(piho_fly_handle* h, const uint8_t* mask, int hard) { piho_fly_reset_ex(h, mask, hard, 0); }
+void piho_fly_get_pgs_iters(const piho_fly_handle* h, int32_t* out) { for (int e = 0; e < h->cfg.n_envs; e++) out[e] = h->env[e].pgs_iters; }
 void piho_fly_step(piho_fly_handle* h, const real* actions, real* obs, real* reward, uint8_t* done) {
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 16)

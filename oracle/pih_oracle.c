@@ -464,6 +464,7 @@ typedef struct {
   int ncache; int cache_key[CMAX]; real cache_lambda[CMAX];
   int ncontacts; Contact contacts[CMAX]; real lambda_n[CMAX];
   real contact_force; real tip[7]; real udot[ND];
+  int pgs_iters; real pgs_res2;   /* iterations executed; largest squared row residual of the LAST iteration */
 } Env;
 #ifdef _OPENMP
 #include <omp.h>
@@ -474,12 +475,18 @@ static int omp_tid(void) { return 0; }
 static int omp_nt(void) { return 1; }
 #endif
 #define MAXTHREADS 512
-struct piho_handle { piho_config cfg; Env* env; void* rows_ws[MAXTHREADS]; };
+struct piho_handle { piho_config cfg; Env* env; void* rows_ws[MAXTHREADS]; int rewind_pending; };
+/* is the early-exit test evaluated after iteration `it` (1-based) of `iters`?  stride 1: always (Bullet); s > 1: the product's sampled
+ * cadence (peg_in_hole_gym_amd/csrc/pih_wave.h pgs_iteration_loop): iterations 1..4, 4 + s k, and the last one */
+static int exit_checked(int it, int iters, int stride) {
+  if (stride <= 1 || it <= 4 || it == iters) return 1;
+  return (it - 4) % stride == 0;
+}
 
 void piho_default_config(piho_config* c) {
   memset(c, 0, sizeof *c);
   c->n_envs = 1; c->mode = 0; c->solver_iters = 50; c->ik_iters = 20; c->max_episode_steps = 2227; c->auto_reset = 0;
-  c->enable_self_collision = 1; c->enable_arm_collision = 3; c->seed = 0; c->dt = 1.0 / 240.0; c->residual_threshold = 1e-7; c->erp = 0.2;
+  c->enable_self_collision = 1; c->enable_arm_collision = 3; c->exit_check_stride = 1; c->seed = 0; c->dt = 1.0 / 240.0; c->residual_threshold = 1e-7; c->erp = 0.2;
   c->warmstart = 0.85; c->contact_margin = 0.005; c->linear_slop = 1e-5; c->ik_damping = 0.5; c->ik_residual = 1e-4;
   c->dv = 2.0 / 240.0;
 }
@@ -549,16 +556,19 @@ static void reset_env(piho_handle* h, int e) {
   fk(&s[PIHO_S_QARM], &s[PIHO_S_POS], &s[PIHO_S_QUAT], &s[PIHO_S_QJ], ANL, NL, K);
   tip_pose(E, K, E->tip);
 }
-void piho_reset(piho_handle* h, const uint8_t* mask) {
-  for (int e = 0; e < h->cfg.n_envs; e++) if (!mask || mask[e]) reset_env(h, e);
-}
-void piho_reset_hard(piho_handle* h, const uint8_t* mask) {
+void piho_reset_ex(piho_handle* h, const uint8_t* mask, int hard, uint64_t seed);
+void piho_reset(piho_handle* h, const uint8_t* mask) { piho_reset_ex(h, mask, 0, 0); }
+void piho_reset_ex(piho_handle* h, const uint8_t* mask, int hard, uint64_t seed) {
+  if (seed != 0) { h->cfg.seed = seed; h->rewind_pending = 1; }
+  const int rewind = h->rewind_pending; h->rewind_pending = 0;
   for (int e = 0; e < h->cfg.n_envs; e++) if (!mask || mask[e]) {
-    h->env[e].s[PIHO_S_RNG] = 0; h->env[e].s[PIHO_S_RNG_HI] = 0; h->env[e].s[PIHO_S_SPARE] = 0;
+    if (hard) h->env[e].s[PIHO_S_SPARE] = 0;                       /* resetSimulation: a new scene like any reset (envs/base_env.py:85-94) */
+    if (rewind) { h->env[e].s[PIHO_S_RNG] = 0; h->env[e].s[PIHO_S_RNG_HI] = 0; }   /* explicit replay */
     reset_env(h, e);
   }
 }
-void piho_reseed(piho_handle* h, uint64_t seed) { h->cfg.seed = seed; }
+void piho_reset_hard(piho_handle* h, const uint8_t* mask) { piho_reset_ex(h, mask, 1, 0); }
+void piho_reseed(piho_handle* h, uint64_t seed) { h->cfg.seed = seed; h->rewind_pending = 1; }
 
 /* ------------------------------------------------------------------------------------------ collision */
 static int add_contact(Env* E, int linkA, int linkB, int key, const v3 p, const v3 n, real depth, real mu) {
@@ -896,8 +906,10 @@ static void step_env(piho_handle* h, int e, const real* action, real* obs, real*
   /* ---- sequential impulse (Bullet resolveSingleConstraintRowGeneric form) */
   real dv[ND]; memset(dv, 0, sizeof dv);
   for (int i = 0; i < nc; i++) { const Row* r = &rows[row_n0 + 3 * i]; if (r->lambda != 0) for (int k = 0; k < ND; k++) dv[k] += r->W[k] * r->lambda; }
+  E->pgs_iters = 0;
   for (int it = 0; it < c->solver_iters; it++) {
     real res2 = 0;
+    E->pgs_iters = it + 1;
     for (int i = 0; i < nr; i++) {
       Row* r = &rows[i];
       if (r->fparent >= 0) {
@@ -915,7 +927,8 @@ static void step_env(piho_handle* h, int e, const real* action, real* obs, real*
       for (int k = 0; k < ND; k++) dv[k] += r->W[k] * dl;
       real rs = dl / r->dinv; if (rs * rs > res2) res2 = rs * rs;
     }
-    if (res2 <= c->residual_threshold) break;
+    E->pgs_res2 = res2;
+    if (exit_checked(it + 1, c->solver_iters, c->exit_check_stride) && res2 <= c->residual_threshold) break;
   }
   for (int i = 0; i < ND; i++) u[i] += dv[i];
   /* btMultiBody m_maxCoordinateVelocity = 100 on EVERY coordinate velocity, floating base included [UNVERIFIED App. C];
@@ -1151,6 +1164,28 @@ void piho_set_state(piho_handle* h, const real* in) {
 }
 void piho_get_tip_pose(const piho_handle* h, real* out) { for (int e = 0; e < h->cfg.n_envs; e++) memcpy(out + 7 * e, h->env[e].tip, sizeof(real) * 7); }
 void piho_get_contact_force(const piho_handle* h, real* out) { for (int e = 0; e < h->cfg.n_envs; e++) out[e] = h->env[e].contact_force; }
+void piho_get_pgs_iters(const piho_handle* h, int32_t* out) { for (int e = 0; e < h->cfg.n_envs; e++) out[e] = h->env[e].pgs_iters; }
+void piho_get_pgs_residual(const piho_handle* h, real* out) { for (int e = 0; e < h->cfg.n_envs; e++) out[e] = h->env[e].pgs_res2; }
+void piho_get_warm_cache(const piho_handle* h, real* out) {
+  for (int e = 0; e < h->cfg.n_envs; e++) {
+    const Env* E = &h->env[e]; real* o = out + (size_t)e * 97;
+    o[0] = (real)E->ncache;
+    for (int k = 0; k < CMAX; k++) { o[1 + k] = k < E->ncache ? (real)E->cache_key[k] : (real)-1; o[1 + CMAX + k] = k < E->ncache ? E->cache_lambda[k] : (real)0; }
+  }
+}
+int piho_debug_contacts(const piho_handle* h, int env, real* out);
+void piho_set_warm_cache(piho_handle* h, const real* in) {
+  for (int e = 0; e < h->cfg.n_envs; e++) {
+    Env* E = &h->env[e]; const real* o = in + (size_t)e * 97;
+    int n = (int)o[0]; if (n < 0) n = 0; if (n > CMAX) n = CMAX;
+    E->ncache = n;
+    for (int k = 0; k < n; k++) { E->cache_key[k] = (int)o[1 + k]; E->cache_lambda[k] = o[1 + CMAX + k]; }
+  }
+}
+void piho_debug_contacts_all(const piho_handle* h, real* out, int32_t* counts) {
+  memset(out, 0, sizeof(real) * (size_t)h->cfg.n_envs * CMAX * 12);
+  for (int e = 0; e < h->cfg.n_envs; e++) counts[e] = piho_debug_contacts(h, e, out + (size_t)e * CMAX * 12);
+}
 void piho_get_ncontacts(const piho_handle* h, int32_t* out) { for (int e = 0; e < h->cfg.n_envs; e++) out[e] = h->env[e].ncontacts; }
 int piho_debug_contacts(const piho_handle* h, int env, real* out) {
   const Env* E = &h->env[env];

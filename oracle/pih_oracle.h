@@ -49,6 +49,9 @@ typedef struct {
   int32_t env_index0;         /* global index of env 0 (block partition across ranks): env seeds = seed + 1000 + global index */
   int32_t attach_ball;        /* 0 (default): p7 attach = 6-row weld honouring childFrameOrientation; 1: 3-row ball joint (round-1 behaviour) */
   int32_t enable_arm_collision; /* arm collision spheres (pih_model.h PIH_ARM_SPH_*): bit 0 vs the table plane, bit 1 vs the pipe; default 3 */
+  int32_t exit_check_stride;  /* cadence of the PGS early-exit test: 1 (default) = after every iteration, as Bullet does; s > 1 = the product's
+                                 sampled cadence (include/pih.h pih_config.exit_check_stride): iterations 1..4, then 4 + s k, and the last one */
+  int32_t reserved_i;
   uint64_t seed;
   piho_real dt;                  /* 1/240 */
   piho_real residual_threshold;  /* 1e-7 (squared velocity residual), 0 = never exit early */
@@ -67,8 +70,17 @@ void piho_default_config(piho_config* c);
 piho_handle* piho_create(const piho_config* c, const piho_real* offsets /* [n,3] or NULL */);
 void piho_destroy(piho_handle* h);
 void piho_reset(piho_handle* h, const uint8_t* mask /* [n] or NULL = all */);
-void piho_reset_hard(piho_handle* h, const uint8_t* mask);   /* also forgets the RNG draw counter and the non-finite-reset count */
-void piho_reseed(piho_handle* h, uint64_t seed);
+void piho_reset_hard(piho_handle* h, const uint8_t* mask);   /* resetSimulation (envs/base_env.py:85-86): a NEW scene like any reset; also clears the non-finite-reset count */
+/* same contract as pih_reset (include/pih.h): seed != 0 = explicit replay (new base seed, the reset envs restart their draw sequence) */
+void piho_reset_ex(piho_handle* h, const uint8_t* mask, int hard, uint64_t seed);
+void piho_reseed(piho_handle* h, uint64_t seed);             /* new base seed; the envs reset by the NEXT reset call restart their draw sequence */
+void piho_get_pgs_iters(const piho_handle* h, int32_t* out /* [n] PGS iterations executed in the last step */);
+void piho_get_pgs_residual(const piho_handle* h, piho_real* out /* [n] largest squared row residual (velocity units) of the last PGS iteration executed */);
+/* warm-start contact cache in the layout of the product's state words 128..224: out [n, 97] = count, 48 keys (-1 = none), 48 normal impulses */
+void piho_get_warm_cache(const piho_handle* h, piho_real* out);
+void piho_set_warm_cache(piho_handle* h, const piho_real* in /* [n, 97], same layout */);
+/* contact lists of ALL envs from the last step: out [n, CMAX, 12] (rows as piho_debug_contacts, unused rows zero), counts [n] */
+void piho_debug_contacts_all(const piho_handle* h, piho_real* out, int32_t* counts);
 /* actions [n,4]; obs [n,5]; reward [n]; done [n] */
 void piho_step(piho_handle* h, const piho_real* actions, piho_real* obs, piho_real* reward, uint8_t* done);
 void piho_get_state(const piho_handle* h, piho_real* out /* [n,128] */);
@@ -118,7 +130,9 @@ enum {   /* identical to the product's record (include/pih.h PIH_F_*) */
 typedef struct piho_fly_handle piho_fly_handle;
 piho_fly_handle* piho_fly_create(const piho_config* c, const piho_real* offsets /* [n,3] or NULL */);
 void piho_fly_destroy(piho_fly_handle* h);
-void piho_fly_reset(piho_fly_handle* h, const uint8_t* mask, int hard);
+void piho_fly_reset(piho_fly_handle* h, const uint8_t* mask, int hard);   /* hard: new scene as well, clears the non-finite-reset count */
+void piho_fly_reset_ex(piho_fly_handle* h, const uint8_t* mask, int hard, uint64_t seed);   /* seed != 0: explicit replay, as piho_reset_ex */
+void piho_fly_get_pgs_iters(const piho_fly_handle* h, int32_t* out);
 /* actions [n,6]; obs [n,6]; reward [n]; done [n] */
 void piho_fly_step(piho_fly_handle* h, const piho_real* actions, piho_real* obs, piho_real* reward, uint8_t* done);
 void piho_fly_get_state(const piho_fly_handle* h, piho_real* out /* [n,48] */);

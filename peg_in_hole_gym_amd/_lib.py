@@ -16,7 +16,7 @@ S_QARM, S_QDARM, S_POS, S_QUAT, S_VLIN, S_VANG, S_QJ, S_QDJ, S_TARGET = 0, 9, 18
 S_FSM, S_FSMT, S_DONE, S_GRASP, S_RANDY, S_RNG_HI, S_RNG, S_STEPS, S_OFFSET = 86, 87, 88, 89, 90, 91, 92, 93, 94
 S_SPARE, S_TIP, S_CFORCE, S_NCONTACT, S_PGS_ITERS, S_INVALID, S_CACHE_N = 97, 98, 105, 106, 107, 112, 128
 TASK_PEG_IN_HOLE, TASK_RANDOM_FLY = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = ["pih_default_config", "pih_abi_version", "pih_task_dims", "pih_create", "pih_destroy", "pih_reset", "pih_reseed", "pih_step", "pih_step_n",
            "pih_get_state", "pih_set_state", "pih_ik", "pih_ik_ur5", "pih_render", "pih_render_ex", "pih_grasp_labels", "pih_timing", "pih_timing2", "pih_set_timing", "pih_last_error"]
@@ -26,7 +26,7 @@ class PihConfig(C.Structure):
     """struct pih_config (include/pih.h)"""
     _fields_ = [("n_envs", C.c_int32), ("env_index0", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32),
                 ("ik_iters", C.c_int32), ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32),
-                ("enable_self_collision", C.c_int32), ("debug", C.c_int32), ("schedule", C.c_int32), ("enable_arm_collision", C.c_int32), ("task_id", C.c_int32), ("solver_path", C.c_int32), ("attach_ball", C.c_int32), ("seed", C.c_uint64),
+                ("enable_self_collision", C.c_int32), ("debug", C.c_int32), ("schedule", C.c_int32), ("enable_arm_collision", C.c_int32), ("task_id", C.c_int32), ("solver_path", C.c_int32), ("attach_ball", C.c_int32), ("exit_check_stride", C.c_int32), ("reserved_i", C.c_int32), ("seed", C.c_uint64),
                 ("dt", C.c_float), ("residual_threshold", C.c_float), ("erp", C.c_float), ("warmstart", C.c_float),
                 ("contact_margin", C.c_float), ("linear_slop", C.c_float), ("ik_damping", C.c_float), ("ik_residual", C.c_float),
                 ("dv", C.c_float), ("reserved_f", C.c_float * 3)]
@@ -58,7 +58,7 @@ def load():
     L.pih_task_dims.argtypes = [C.c_int, C.POINTER(C.c_int32 * 3)]
     L.pih_create.argtypes = [C.POINTER(PihConfig), vp, C.POINTER(vp)]
     L.pih_destroy.argtypes = [vp]
-    L.pih_reset.argtypes = [vp, vp, C.c_int, vp]
+    L.pih_reset.argtypes = [vp, vp, C.c_int, C.c_uint64, vp]
     L.pih_step.argtypes = [vp, vp, vp, vp, vp, vp]
     L.pih_step_n.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.pih_get_state.argtypes = [vp, C.c_int, vp, vp]

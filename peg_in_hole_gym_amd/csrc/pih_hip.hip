@@ -85,7 +85,9 @@ __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __rest
   if (lane == 0) { if (reward) reward[env] = r; if (done) done[env] = d; }
 }
 
-__global__ void __launch_bounds__(64) pih_reset_kernel(Params P, float* __restrict__ state, const unsigned char* __restrict__ mask, int hard) {
+// hard (resetSimulation, envs/base_env.py:85-86): a NEW scene like every reset (the reference keeps drawing from the global `random`); it
+// also clears the non-finite-reset count.  rewind (explicit replay, pih_reset(seed != 0) / pih_reseed): the env's draw counter restarts.
+__global__ void __launch_bounds__(64) pih_reset_kernel(Params P, float* __restrict__ state, const unsigned char* __restrict__ mask, int hard, int rewind) {
   __shared__ Shared sh;
   const int env = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[env]) return;
@@ -93,7 +95,8 @@ __global__ void __launch_bounds__(64) pih_reset_kernel(Params P, float* __restri
   float* rec = state + (size_t)env * PIH_STATE_WORDS;
   for (int i = 0; i < PIH_STATE_WORDS / 64; i++) sh.S[lane + 64 * i] = rec[lane + 64 * i];
   __syncthreads();
-  if (hard) { sh.S[PIH_S_RNG] = 0; sh.S[PIH_S_RNG_HI] = 0; sh.S[PIH_S_SPARE] = 0; }   // resetSimulation: replay the seed's scene sequence from the start
+  if (hard) sh.S[PIH_S_SPARE] = 0;
+  if (rewind) { sh.S[PIH_S_RNG] = 0; sh.S[PIH_S_RNG_HI] = 0; }
   __syncthreads();
   reset_state(sh.S, P, P.env0 + env);
   __syncthreads();
@@ -244,13 +247,14 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
   if (done) done[env] = d;
 }
 
-__global__ void __launch_bounds__(64) pih_fly_reset_kernel(Params P, float* __restrict__ state, const unsigned char* __restrict__ mask, int hard, int n) {
+__global__ void __launch_bounds__(64) pih_fly_reset_kernel(Params P, float* __restrict__ state, const unsigned char* __restrict__ mask, int hard, int rewind, int n) {
   const int env = blockIdx.x * 64 + threadIdx.x;
   if (env >= n || (mask && !mask[env])) return;
   float S[fly::SW];
 #pragma unroll
   for (int w = 0; w < fly::SW; w++) S[w] = state[(size_t)w * n + env];
-  if (hard) { S[PIH_F_RNG] = 0; S[PIH_F_RNG_HI] = 0; S[PIH_F_SPARE] = 0; }
+  if (hard) S[PIH_F_SPARE] = 0;
+  if (rewind) { S[PIH_F_RNG] = 0; S[PIH_F_RNG_HI] = 0; }
   fly::reset_state(S, P, P.env0 + env);
 #pragma unroll
   for (int w = 0; w < fly::SW; w++) state[(size_t)w * n + env] = S[w];
@@ -285,6 +289,7 @@ struct pih_handle {
   int device = 0;
   int sched_k = 0, sched_heads = 0;   // config.schedule = 2: light seeds in the first wave of blocks (see pih_pre_kernel)
   bool fly = false;         // PIH_TASK_RANDOM_FLY: structure-of-arrays state, one env per lane
+  bool rewind_pending = false;   // pih_reseed: the envs reset by the next pih_reset restart their draw sequence
   int words = PIH_STATE_WORDS;
   float* state = nullptr;
   float* dbg = nullptr;
@@ -326,6 +331,7 @@ static Params make_params(const pih_config* c) {
   P.slop = c->linear_slop; P.ikdamp = c->ik_damping; P.ikres = c->ik_residual; P.dv = c->dv; P.iters = c->solver_iters;
   P.ikiters = c->ik_iters; P.mode = c->mode; P.maxsteps = c->max_episode_steps; P.autoreset = c->auto_reset;
   P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball; P.noprio = (c->schedule & 4) != 0;
+  P.checkstride = c->exit_check_stride < 1 ? 1 : c->exit_check_stride;
   return P;
 }
 
@@ -347,7 +353,7 @@ extern "C" {
 void pih_default_config(pih_config* c) {
   memset(c, 0, sizeof *c);
   c->n_envs = 1; c->env_index0 = 0; c->mode = 0; c->solver_iters = 50; c->ik_iters = 20; c->max_episode_steps = 2227;
-  c->auto_reset = 0; c->enable_self_collision = 1; c->enable_arm_collision = 3; c->task_id = PIH_TASK_PEG_IN_HOLE; c->debug = 0; c->schedule = 1; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
+  c->auto_reset = 0; c->enable_self_collision = 1; c->enable_arm_collision = 3; c->task_id = PIH_TASK_PEG_IN_HOLE; c->debug = 0; c->schedule = 1; c->exit_check_stride = 16; c->seed = 0; c->dt = 1.0f / 240.0f; c->residual_threshold = 1e-7f;
   c->erp = 0.2f; c->warmstart = 0.85f; c->contact_margin = 0.005f; c->linear_slop = 1e-5f; c->ik_damping = 0.5f; c->ik_residual = 1e-4f;
   c->dv = 2.0f / 240.0f;
 }
@@ -385,7 +391,7 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
   if (h->fly) {
     const int nb64 = (cfg->n_envs + 63) / 64;
     hipLaunchKernelGGL(pih_fly_init_offsets_kernel, dim3(nb64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
-    hipLaunchKernelGGL(pih_fly_reset_kernel, dim3(nb64), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0, cfg->n_envs);
+    hipLaunchKernelGGL(pih_fly_reset_kernel, dim3(nb64), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0, 0, cfg->n_envs);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipDeviceSynchronize());
     return 0;
@@ -396,12 +402,11 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
   if ((cfg->schedule & 3) == 2) {
     int cus = 0; HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     const int slots = 8 * cus;                    // two 256-VGPR wavefronts on each of the 4 SIMDs of a CU
-    h->sched_k = slots / 16;
-    if (const char* e = getenv("PIH_SCHED_K")) h->sched_k = atoi(e);      // measurement override
+    h->sched_k = slots / 16;                      // (0 < sched_k < slots by construction; pih_pre_kernel ignores it unless n > slots)
     h->sched_heads = slots - h->sched_k;
   }
   hipLaunchKernelGGL(pih_init_offsets_kernel, dim3((cfg->n_envs + 63) / 64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
-  hipLaunchKernelGGL(pih_reset_kernel, dim3(cfg->n_envs), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0);
+  hipLaunchKernelGGL(pih_reset_kernel, dim3(cfg->n_envs), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0, 0);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipDeviceSynchronize());
   return 0;
@@ -426,18 +431,21 @@ int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** ou
   return 0;
 }
 
-int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, void* stream) {
+int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, uint64_t seed, void* stream) {
   if (!h) return -2;
   PIH_ENTER(h);
-  if (h->fly) hipLaunchKernelGGL(pih_fly_reset_kernel, dim3((h->cfg.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, h->state, mask_dev, hard != 0, h->cfg.n_envs);
-  else hipLaunchKernelGGL(pih_reset_kernel, dim3(h->cfg.n_envs), dim3(64), 0, (hipStream_t)stream, h->P, h->state, mask_dev, hard != 0);
+  if (seed != 0) { h->cfg.seed = seed; h->P.seed = seed; h->rewind_pending = true; }
+  const int rewind = h->rewind_pending ? 1 : 0;
+  h->rewind_pending = false;
+  if (h->fly) hipLaunchKernelGGL(pih_fly_reset_kernel, dim3((h->cfg.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, h->state, mask_dev, hard != 0, rewind, h->cfg.n_envs);
+  else hipLaunchKernelGGL(pih_reset_kernel, dim3(h->cfg.n_envs), dim3(64), 0, (hipStream_t)stream, h->P, h->state, mask_dev, hard != 0, rewind);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
 
 int pih_reseed(pih_handle* h, uint64_t seed) {
   if (!h) return -2;
-  h->cfg.seed = seed; h->P.seed = seed;
+  h->cfg.seed = seed; h->P.seed = seed; h->rewind_pending = true;
   return 0;
 }
 

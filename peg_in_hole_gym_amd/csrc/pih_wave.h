@@ -271,10 +271,6 @@ PIH_HD void pull_motor_rows(Wave& w, Shared& sh, MotorW& mw) {
 // => lanes 32..47 hold the sum over lanes 0..47 (all 38 DOF lanes).  Written as inline asm because hipcc lowers the
 // masked-row form to v_mov 0 + v_mov_dpp + v_add (3 instructions) instead of one fused v_add_f32_dpp; the s_nop covers the
 // VALU-write -> DPP-read hazard that the compiler does not pad inside asm.
-#ifndef PIH_DPP_ASM
-#define PIH_DPP_ASM 1
-#endif
-#if PIH_DPP_ASM
 PIH_HD void rows012_total3(real& a, real& b, real& c) {
   __asm__ volatile("s_nop 1\n\t"
                    "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\t"
@@ -287,15 +283,6 @@ PIH_HD void rows012_total3(real& a, real& b, real& c) {
                    "s_nop 1"
                    : "+v"(a), "+v"(b), "+v"(c));
 }
-#else
-template <int CTRL, int ROWMASK> PIH_HD real dpp_add_rows(real x) {
-  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, false));
-}
-PIH_HD void rows012_total3(real& a, real& b, real& c) {
-  a = dpp_add_rows<0x142, 0xA>(a); b = dpp_add_rows<0x142, 0xA>(b); c = dpp_add_rows<0x142, 0xA>(c);
-  a = dpp_add_rows<0x143, 0xC>(a); b = dpp_add_rows<0x143, 0xC>(b); c = dpp_add_rows<0x143, 0xC>(c);
-}
-#endif
 // after this every lane holds the sum over its 16-lane row; three independent reductions interleaved for ILP
 PIH_HD void row16_sum3(real& a, real& b, real& c) {
   a = dpp_add<0xB1>(a); b = dpp_add<0xB1>(b); c = dpp_add<0xB1>(c);        // quad_perm [1,0,3,2]
@@ -318,19 +305,24 @@ PIH_HD void row16_sum3(real& a, real& b, real& c) {
 // limit; the 23 pipe motors; per contact: normal, dir1, dir2).  The DOF velocities are recovered at the end as du = sum_i W_i
 // lambda_i.  The arm-row and pipe-row columns are disjoint (A[arm][pipe motor] = 0), so the motor chain runs on two accumulators
 // for ILP exactly like the DOF-space chain.  (tools/micro/rowchain.hip times the row chain in isolation.)
-// The iteration loop of both solvers.  Bullet's early exit (largest squared row residual <= 1e-7) is evaluated in the first four
-// iterations -- where it actually fires: envs in free flight converge in two -- and after that in every 16th iteration and in the
-// last one; in between the body runs without the per-row compare (one v_cmp + one scalar OR per row, ~15 % of a row update).  An
-// env that would have met the threshold between two checks performs at most 15 extra iterations whose updates are all below the
-// threshold; with residual_threshold = 0 (every parity test) nothing changes.  The unchecked body is instantiated twice per trip:
-// the multipliers are loop-carried, and with a single copy every new value is moved back into the register the loop header expects.
-template <bool DOUBLED = true, class FC, class FN> PIH_HD int pgs_iteration_loop(int iters, FC checked, FN unchecked) {
+// The iteration loop of all three solvers and the cadence of Bullet's early exit (largest squared row residual <= residual_threshold).
+// Bullet evaluates the test after EVERY iteration; `stride` = pih_config.exit_check_stride selects how often the product does:
+//   stride = 1: every iteration (Bullet's cadence);
+//   stride = s > 1 (default 16): iterations 1..4 -- where it actually fires: envs in free flight converge in two -- then iterations
+//   4 + s k and the last one; in between the body runs without the per-row compare (one v_cmp + one scalar OR per row, ~15 % of a row
+//   update).  An env that would have met the threshold between two tests performs at most s - 1 further iterations whose updates are
+//   all below the threshold.  The oracle has the same switch (piho_config.exit_check_stride); tests/test_gpu_defaults.py compares the
+//   product at its defaults with the oracle at both cadences.
+// The unchecked body is instantiated twice per trip: the multipliers are loop-carried, and with a single copy every new value is
+// moved back into the register the loop header expects.
+template <bool DOUBLED = true, class FC, class FN> PIH_HD int pgs_iteration_loop(int iters, int stride, FC checked, FN unchecked) {
   int it = 0;
-  // iterations 1..4 with the test
-  while (it < iters && it < 4) { it++; if (checked()) return it; }
-  // then groups of sixteen: fifteen without, one with (the last iteration always with)
+  const int lead = stride <= 1 ? iters : 4;
+  // iterations 1..lead with the test
+  while (it < iters && it < lead) { it++; if (checked()) return it; }
+  // then groups of `stride`: stride - 1 without, one with (the last iteration always with)
   while (it < iters) {
-    const int stop = it + 15 < iters - 1 ? it + 15 : iters - 1;
+    const int stop = it + stride - 1 < iters - 1 ? it + stride - 1 : iters - 1;
     if (DOUBLED) {
       while (it < stop) {
         it++; unchecked();
@@ -451,6 +443,9 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
     skip7 = skip7 && sh.mrec[0][3] >= (real)100;
     skip7 = __builtin_amdgcn_readfirstlane((int)skip7) != 0;
   }
+  real armlim = sh.mrec[0][3];
+#pragma unroll
+  for (int j = 1; j < 7; j++) armlim = sh.mrec[j][3] < armlim ? sh.mrec[j][3] : armlim;
   if (lane < 9) sh.lrec[lane][3] = sh.lrec[lane][2] * sh.mrec[lane][0];          // (J W) dinv of the arm joint (1 up to rounding)
   w.sync();
   // ---- multipliers: arm rows wave-uniform in VGPRs, every other row in its own lane
@@ -473,7 +468,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
         if (c < nc) v += Bn[NMOT + 3 * c] * sh.r_lam[3 * c];
       z = rhs + v;                         // (Bn = [own] - dinv A: the sum is  [own normal row] lam0 - dinv (J du))
     }
-    unsigned long long clamped = 0;
+    real amax = 0;                           // largest |multiplier| any arm motor row 0..6 took during the solve (limit rows left out)
     auto iterate = [&](auto CHECKTAG) __attribute__((always_inline)) -> bool {
       constexpr bool CHECK = decltype(CHECKTAG)::value;     // evaluate the early-exit test in this iteration? (see pgs_iteration_loop)
       unsigned long long busy = 0;
@@ -507,7 +502,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
             if (CHECK) busy |= __ballot(absr(d3) > th);
             za += Bn[j] * (dl + d2 - d3);
           } else {
-            if (CHECK) clamped |= __ballot(absr(sum) >= lim);     // watched in the checked iterations (a multiplier at its bound stays there)
+            amax = max_(amax, absr(sum));                         // watched in EVERY iteration (one v_max): a multiplier may touch its bound and leave it again
             za += Bn[j] * dl;
           }
         }
@@ -557,8 +552,8 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       }
       return CHECK && busy == 0;
     };
-    it = pgs_iteration_loop(P.iters, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
-    return clamped != 0;
+    it = pgs_iteration_loop(P.iters, P.checkstride, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
+    return __builtin_amdgcn_readfirstlane(amax >= armlim ? 1 : 0) != 0;   // (armlim = the smallest bound of rows 0..6: conservative if they differ, exact if equal)
   };
   int variant = 1;
   if (!skip7) { solve(std::true_type{}); variant = 2; }
@@ -826,7 +821,7 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
     z0 = pk_lo(zz); z1 = pk_hi(zz);
     return CHECK && busy == 0;
   };
-  const int it = pgs_iteration_loop<false>(P.iters, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
+  const int it = pgs_iteration_loop<false>(P.iters, P.checkstride, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
   if (lane == 0) sh.S[PIH_S_SOLVER] = 5;
   // ---- multipliers back to LDS, DOF velocities du = sum_i W_i lambda_i
   if (lane >= NMOT && lane < NMOT + 3 * nc) sh.r_lam[lane - NMOT] = lam0;
@@ -1029,7 +1024,7 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
     }
     return CHECK && !((busy >> 32) & 1ull);
   };
-  const int it = pgs_iteration_loop(P.iters, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
+  const int it = pgs_iteration_loop(P.iters, P.checkstride, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
   w.sync();
   if (d < nc) { const real* R = d < CL ? sh.b.crec[d] : ov.base + OVF_W_WORDS + (size_t)(d - CL) * CREC; sh.r_lam[3 * d] = R[26]; sh.r_lam[3 * d + 1] = R[27]; sh.r_lam[3 * d + 2] = R[28]; }
   if (d < ND) sh.u[d] += du;

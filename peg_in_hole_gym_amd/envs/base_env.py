@@ -36,11 +36,25 @@ def _to_numpy(x):
     return np.asarray(x)
 
 
-def _reset_backend(backend, hard_reset):
-    """BaseEnv.reset(hard_reset) (envs/base_env.py:84-94): hard = resetSimulation, here also a restart of the seed's scene sequence"""
+def backend_accepts_hard_reset(backend):
+    """Decided ONCE, from the signature: does backend.reset take `hard_reset`?  (No try/except around the call itself: a TypeError
+    raised inside a backend's reset must propagate, not turn into a silent soft reset.)"""
+    import inspect
     try:
+        params = inspect.signature(backend.reset).parameters
+    except (TypeError, ValueError):
+        return False
+    return "hard_reset" in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+
+def _reset_backend(backend, hard_reset, accepts_hard=None):
+    """BaseEnv.reset(hard_reset) (envs/base_env.py:84-94): hard = resetSimulation + reload.  Soft or hard, every agent gets a NEW random
+    scene (the reference draws from the global `random` in both cases, envs/peg_in_hole.py:239-267)."""
+    if accepts_hard is None:
+        accepts_hard = backend_accepts_hard_reset(backend)
+    if accepts_hard:
         backend.reset(None, hard_reset=bool(hard_reset))
-    except TypeError:      # a backend without the keyword
+    else:
         backend.reset(None)
 
 
@@ -90,6 +104,7 @@ class BaseEnv(object):
         kw.update(cfg)
         self._adim = self.sub_env.action_space.shape[0]
         self._backend = factory(task_num, env_offsets(offset, task_num), **kw)
+        self._hard_ok = backend_accepts_hard_reset(self._backend)
 
     # --- reference API -------------------------------------------------------------------------------------------
     def reset(self, hard_reset=False):
@@ -129,7 +144,7 @@ class BaseEnv(object):
 
     # --- helpers -------------------------------------------------------------------------------------------------
     def _reset_backend(self, hard_reset):
-        _reset_backend(self._backend, hard_reset)
+        _reset_backend(self._backend, hard_reset, self._hard_ok)
 
     @property
     def invalid(self):

@@ -3,8 +3,8 @@ nesting (envs/base_env_mp.py:7-87).  The reference forks mp_num processes and pi
 Queue(1) pairs; here every agent is one wavefront of ONE batched launch, so there are no worker processes at all."""
 import numpy as np
 
-from .base_env import (IMG_SHAPE, TASK_LIST, _MODES, _default_backend, _reset_backend, _to_numpy, obs_after_reset, scripted_episode,
-                       task_backend_cfg)
+from .base_env import (IMG_SHAPE, TASK_LIST, _MODES, _default_backend, _reset_backend, _to_numpy, backend_accepts_hard_reset, obs_after_reset,
+                       scripted_episode, task_backend_cfg)
 from .utils import (MultiAgentActionSpace, MultiAgentObservationSpace, MPMultiAgentActionSpace,
                     MPMultiAgentObservationSpace, env_offsets)
 
@@ -43,9 +43,10 @@ class BaseEnvMp(object):
             kw["dv"] = 0.05
         kw.update(cfg)
         self._backend = factory(self.n, offs, **kw)
+        self._hard_ok = backend_accepts_hard_reset(self._backend)
 
     def _reset_backend(self, hard_reset):
-        _reset_backend(self._backend, hard_reset)
+        _reset_backend(self._backend, hard_reset, self._hard_ok)
 
     @property
     def invalid(self):

@@ -36,6 +36,9 @@ class MetaEnv(object):
             self._backend = backend_factory(1, self.offset.reshape(1, 3), task_id=self.task_id, **kw)
         self._action = np.zeros(self.action_space.shape, dtype=np.float32)
         self.done = False
+        import inspect      # decided once from the signature (a TypeError raised INSIDE a backend's reset must propagate)
+        params = inspect.signature(self._backend.reset).parameters
+        self._hard_ok = "hard_reset" in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
 
     def _load_models(self):
         """The reference loads URDFs here; the model tables are baked into the kernel (include/pih_model.h)."""
@@ -64,9 +67,9 @@ class MetaEnv(object):
     def reset(self, hard_reset=False):
         if hard_reset:
             self._load_models()
-        try:
+        if self._hard_ok:
             self._backend.reset(None, hard_reset=bool(hard_reset))
-        except TypeError:
+        else:
             self._backend.reset(None)
         self.done = False
 

@@ -59,15 +59,18 @@ class PihVecEnv:
         if rc != 0:
             raise _lib.PihError("%s failed (%d): %s" % (what, rc, self.L.pih_last_error(self.h).decode()))
 
-    def reset(self, mask=None, hard_reset=False):
+    def reset(self, mask=None, hard_reset=False, seed=0):
+        """pih_reset: every reset (soft or hard) draws a NEW scene from the env's own sequence, as the reference does with the global
+        `random` (envs/peg_in_hole.py:239-267); hard_reset (resetSimulation, envs/base_env.py:85-86) also clears the non-finite-reset
+        count.  seed != 0: explicit replay -- new base seed, the reset envs restart their draw sequence from its beginning."""
         m = None
         if mask is not None:
             m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
         with torch.cuda.device(self.device):
-            self._chk(self.L.pih_reset(self.h, m.data_ptr() if m is not None else None, int(hard_reset), self._stream()), "pih_reset")
+            self._chk(self.L.pih_reset(self.h, m.data_ptr() if m is not None else None, int(bool(hard_reset)), int(seed), self._stream()), "pih_reset")
 
     def reseed(self, seed):
-        """New base seed for later resets (env seed = seed + 1000 + global env index); use reset(hard_reset=True) to restart the draws."""
+        """New base seed (env seed = seed + 1000 + global env index); the envs reset by the NEXT reset() restart their draw sequence."""
         self._chk(self.L.pih_reseed(self.h, int(seed)), "pih_reseed")
 
     def invalid(self):

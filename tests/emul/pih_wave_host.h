@@ -212,7 +212,11 @@ PIH_HD int pgs(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const MotorW
         track(dl, di);
       }
     }
-    if (worst <= 0) { it++; break; }
+    // the product's cadence of the early-exit test (pih_wave.h pgs_iteration_loop): stride 1 = every iteration, s > 1 = iterations
+    // 1..4, 4 + s k, and the last one
+    const int itn = it + 1, s = P.checkstride;
+    const bool checked = s <= 1 || itn <= 4 || itn == P.iters || (itn - 4) % s == 0;
+    if (checked && worst <= 0) { it++; break; }
   }
   for (int d = 0; d < ND; d++) sh.u[d] += du[d];
   (void)mw;

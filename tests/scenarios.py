@@ -31,3 +31,13 @@ def stiff_finger_contact(contacts):
     arm = (c[:, 1] >= 0) & (c[:, 1] <= 8) & loaded
     mu10 = (c[:, 9] >= 10.0) & loaded
     return bool(arm.any() and mu10.any())
+
+
+def stiff_mask(contacts, counts):
+    """Vectorised stiff_finger_contact over all envs: contacts [n, CMAX, 12], counts [n] (Oracle.debug_contacts_all) -> bool [n]."""
+    c = np.asarray(contacts); n, m, _ = c.shape
+    live = np.arange(m)[None, :] < np.asarray(counts)[:, None]
+    loaded = live & (c[:, :, 11] > 0)
+    arm = (c[:, :, 1] >= 0) & (c[:, :, 1] <= 8) & loaded
+    mu10 = (c[:, :, 9] >= 10.0) & loaded
+    return arm.any(1) & mu10.any(1)

@@ -66,3 +66,20 @@ def test_bench_gpus_flag_spawns_ranks_end_to_end():
     assert d["config"]["envs_per_gpu"] == 8192 and d["config"]["total_envs"] == 16384 and "all-gather" in d["config"]["parallelism"]
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
         assert k in d
+
+
+def test_bench_eight_gpu_line_is_ready():
+    """BASELINE configs[3] as the driver will launch it on an 8-GPU node: 16384 envs block-sharded over 8 ranks, obs all-gather.  Dry run
+    (no env, gloo): the launcher / barrier / all-gather / max-over-ranks path runs end to end and rank 0's JSON line carries the right shape."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1",
+                          "--preroll", "2", "--total-envs", "16384"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["dry_run"] is True
+    assert d["config"]["envs_per_gpu"] == 2048 and d["config"]["total_envs"] == 16384
+    assert d["config"]["parallelism"].startswith("env-block x8 + ") and d["config"]["parallelism"].endswith("all-gather(obs)")

@@ -82,7 +82,9 @@ def _stable_scenario(oracle_mod, prec, bent):
         maxd = max(maxd, np.abs(o.tip_pose()[:, :3] - se[:, 98:101]).max())
         maxo = max(maxo, np.abs(oo - oe).max())
         fo.append(o.contact_force()); fe.append(se[:, 105].copy())
-    return maxd, force_diffs(np.array(fo), np.array(fe)), maxo
+    from tests import parity_util as P
+    f_avg, f_inst, f_calm, calm_share = P.force_parity(fo, fe)
+    return maxd, (f_inst, f_avg, f_calm, calm_share), maxo
 
 
 def force_diffs(fo, fe, skip=20, win=16):
@@ -97,12 +99,13 @@ def force_diffs(fo, fe, skip=20, win=16):
 def test_trajectory_parity_contact_stable(oracle_mod, bent):
     """north_star tolerance: peg-tip pose within 1e-3 m and contact-normal force within 1e-2 N over 1000 steps on
     identical seeds, contact-stable scenarios (pipe resting on the table while the arm tracks a smooth target)."""
-    d, (f_inst, f_avg), ob = _stable_scenario(oracle_mod, "f32", bent)
-    # force: 1e-2 N on the 16-step (1/15 s) mean; single-step values of the creeping bent pipe jitter a little more
-    # because contacts make/break one step apart in the two simulations
-    assert d < 1e-3 and f_avg < 1e-2 and f_inst < 5e-2 and ob < 1e-3, (d, f_inst, f_avg, ob)
-    d, (f_inst, f_avg), ob = _stable_scenario(oracle_mod, "f64", bent)
-    assert d < 1e-4 and f_avg < 5e-3 and ob < 1e-6, (d, f_inst, f_avg, ob)
+    d, (f_inst, f_avg, f_calm, calm_share), ob = _stable_scenario(oracle_mod, "f32", bent)
+    # force: 1e-2 N on the 16-step (1/15 s) mean AND on the instantaneous value wherever the oracle's own force does not jump by more
+    # than that from one step to the next (tests/parity_util.py force_parity); at such load / unload transients of a listed contact of
+    # the creeping bent pipe the two simulations are a fraction of a step apart and the single-step difference is bounded at 5e-2 N
+    assert d < 1e-3 and f_avg < 1e-2 and f_calm < 1e-2 and calm_share > 0.9 and f_inst < 5e-2 and ob < 1e-3, (d, f_inst, f_avg, f_calm, ob)
+    d, (f_inst, f_avg, f_calm, calm_share), ob = _stable_scenario(oracle_mod, "f64", bent)
+    assert d < 1e-4 and f_avg < 5e-3 and f_calm < 5e-3 and ob < 1e-6, (d, f_inst, f_avg, f_calm, ob)
 
 
 def test_frozen_done_and_auto_reset(oracle_mod):
@@ -248,3 +251,33 @@ def test_operation_counting_build_counts_and_computes_the_same():
     c.L.emul_flops_get(ph, tot)
     per = sum(tot[:5]) / (N * 60)
     assert 1e5 < per < 3e6 and sum(ph[6 * 5:6 * 5 + 5]) > 0.3 * sum(tot[:5])     # PGS is the bulk
+
+
+def test_defaults_parity_on_host_build(oracle_mod):
+    """The check of tests/test_gpu_defaults.py (library defaults: residual_threshold 1e-7, warmstart 0.85, exit_check_stride 16; oracle
+    at Bullet's cadence and at the product's cadence; every env-step bounded, tests/parity_util.py) on the fp32 HOST build of the product
+    algorithm -- the same assertions the HIP library must pass on the GPU box, exercised in the CPU suite."""
+    from tests import parity_util as P
+    E.build()
+    N = 192
+    g = E.Emul(N, "f32", seed=5, exit_check_stride=16)
+    assert abs(g.cfg.residual_threshold - 1e-7) < 1e-12 and abs(g.cfg.warmstart - 0.85) < 1e-6
+    P.defaults_one_step_check("host build (fp32) at the library defaults", oracle_mod, g, N, 130)
+
+
+def test_exit_cadence_of_the_oracle(oracle_mod):
+    """piho_config.exit_check_stride: stride 16 tests the residual in iterations 1..4, 20, 36 and 50 only -- from identical states it runs
+    at least as many iterations as Bullet's cadence, and exits only in a tested iteration; the states differ at the threshold level."""
+    N = 64
+    A = oracle_mod.Oracle(N, omp=True, seed=9); B = oracle_mod.Oracle(N, omp=True, seed=9, exit_check_stride=16)
+    rng = np.random.default_rng(1)
+    seen_early = 0
+    for t in range(60):
+        a = rng.uniform(-1, 1, (N, 4))
+        B.set_state(A.get_state()); B.set_warm_cache(A.warm_cache())
+        A.step(a); B.step(a)
+        ia, ib = A.pgs_iters(), B.pgs_iters()
+        assert (ib >= ia).all() and np.isin(ib, [1, 2, 3, 4, 20, 36, 50]).all()
+        seen_early += int((ia < 50).sum())
+        assert np.abs(A.get_state()[:, :77] - B.get_state()[:, :77]).max() < 1e-2
+    assert seen_early > 100

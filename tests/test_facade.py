@@ -89,3 +89,46 @@ def test_product_default_backend_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(pih.PihError):
         pih.make("peg-in-hole-mp-v0", client=None, task="peg-in-hole", mp_num=2, sub_num=1)
+
+
+def test_hard_reset_draws_a_new_scene_like_the_reference():
+    """envs/base_env.py:84-94 + envs/peg_in_hole.py:239-267: reset(hard_reset=True) = resetSimulation followed by FRESH random.* draws.
+    An unmodified training loop that always resets hard must see a new pipe pose / joint set / grasp joint every episode."""
+    env = BaseEnvMp(client=None, task="peg-in-hole", mp_num=2, sub_num=1, backend_factory=factory, seed=3)
+    scenes = []
+    for _ in range(3):
+        env.reset(hard_reset=True)
+        scenes.append(env._backend.state()[:, 18:20].copy())          # pipe base xy
+    assert not np.allclose(scenes[0], scenes[1]) and not np.allclose(scenes[1], scenes[2]) and not np.allclose(scenes[0], scenes[2])
+    env.reset()                                                        # soft reset: a new scene as well
+    assert not np.allclose(env._backend.state()[:, 18:20], scenes[2])
+    # explicit replay is a separate, deliberate call: reseed -> the next reset restarts that seed's sequence
+    env._backend.reseed(3); env.reset(hard_reset=True)
+    first = BaseEnvMp(client=None, task="peg-in-hole", mp_num=2, sub_num=1, backend_factory=factory, seed=3)
+    np.testing.assert_array_equal(env._backend.state()[:, :98], first._backend.state()[:, :98])
+
+
+def test_type_errors_inside_a_backend_reset_propagate():
+    """Whether a backend takes `hard_reset` is decided once from its signature; a TypeError raised INSIDE reset is a real failure and
+    must not be swallowed and retried as a soft reset."""
+    class Broken:
+        def __init__(self, n, offsets, **cfg):
+            self.n = n
+        def reset(self, mask=None, hard_reset=False):
+            raise TypeError("bad mask dtype")
+        def state(self):
+            return np.zeros((self.n, 256))
+    env = BaseEnv(client=None, task="peg-in-hole", task_num=1, backend_factory=lambda n, o, **kw: Broken(n, o, **kw))
+    with pytest.raises(TypeError, match="bad mask dtype"):
+        env.reset(hard_reset=True)
+
+    class NoKeyword:
+        def __init__(self, n, offsets, **cfg):
+            self.n = n; self.calls = 0
+        def reset(self, mask=None):
+            self.calls += 1
+        def state(self):
+            return np.zeros((self.n, 256))
+    env = BaseEnv(client=None, task="peg-in-hole", task_num=1, backend_factory=lambda n, o, **kw: NoKeyword(n, o, **kw))
+    env.reset(hard_reset=True)
+    assert env._backend.calls == 1

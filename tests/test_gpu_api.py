@@ -41,7 +41,8 @@ def test_masked_reset_and_state_roundtrip(torch_mod):
 
 
 def test_hard_reset_reseed_and_two_handles(torch_mod):
-    """pih_reset(hard=1) restarts the env's draw sequence, pih_reseed changes it; two live handles in one process do not
+    """Like the reference (resetSimulation + fresh random draws, envs/base_env.py:84-94, envs/peg_in_hole.py:239-267), a hard reset gives a
+    NEW scene; replay is explicit (pih_reset(seed != 0) / pih_reseed rewind the draw sequence).  Two live handles in one process do not
     disturb each other (every entry point selects its handle's device and restores the caller's)."""
     torch = torch_mod
     n = 33
@@ -53,9 +54,16 @@ def test_hard_reset_reseed_and_two_handles(torch_mod):
     assert torch.equal(a.state(), b.state())
     a.reset()                                         # soft reset: a NEW scene (counter continues)
     assert not torch.equal(a.state()[:, 18:20], first[:, 18:20])
-    a.reset(hard_reset=True)                          # hard reset: the first scene again, bit for bit
+    second = a.state().clone()
+    a.reset(hard_reset=True)                          # hard reset: again a NEW scene (an unmodified training loop sees fresh scenes)
+    third = a.state().clone()
+    assert not torch.equal(third[:, 18:20], first[:, 18:20]) and not torch.equal(third[:, 18:20], second[:, 18:20])
+    assert (third[:, 92] > second[:, 92]).all()       # the draw counter kept advancing
+    a.reset(hard_reset=True, seed=4)                  # explicit replay: the seed's first scene again, bit for bit
     assert torch.equal(a.state()[:, :98], first[:, :98])
-    a.reseed(77); a.reset(hard_reset=True)
+    a.reset()
+    assert torch.equal(a.state()[:, :98], second[:, :98])      # ... and the same sequence after it
+    a.reseed(77); a.reset(hard_reset=True)            # pih_reseed: new base seed, the next reset starts its sequence
     c = _gpu(n, seed=77)
     assert torch.equal(a.state()[:, :98], c.state()[:, :98]) and not torch.equal(a.state()[:, 18:20], first[:, 18:20])
     assert torch.equal(b.state()[:, 93], torch.full((n,), 5.0, device="cuda"))     # b was never touched by a's resets

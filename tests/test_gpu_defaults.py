@@ -1,0 +1,120 @@
+"""HIP vs oracle AT THE SETTINGS THAT ARE BENCHMARKED AND SHIPPED: pih_default_config's residual_threshold = 1e-7, warmstart = 0.85 and
+exit_check_stride = 16 (the sampled cadence of Bullet's early-exit test, include/pih.h) -- what bench.py, the facade and every user who
+does not override the config run.  The other parity files pin the algorithm with the exit test switched off (residual_threshold = 0);
+here the exit test, the CHECK = true ballot paths of all three PGS variants and the warm start are live.
+
+Three oracles stand beside the product from identical states (physical state AND warm-start cache resynchronised every step):
+  A     Bullet's cadence (test after every iteration)  -> bounds: pose <= 1e-3 m (north_star) as a MAX over the well-conditioned
+        env-steps, contact sets / done flags equal, executed iterations within [A - 1, A + stride]
+  B     the product's cadence (piho_config.exit_check_stride = 16) -> the SAME iteration count except where a residual sits on
+        the threshold
+  probes  for every env-step whose error exceeds 3e-5: 16 fp64 runs from randomly perturbed (1e-6) copies of its input -- the error
+        must stay within max(1e-4, 10 x the oracle's own spread) on EVERY env-step (tests/parity_util.py ConditionedParity).
+The same check runs on the host build of the product algorithm in the CPU suite (tests/test_emul_parity.py).  PARITY UNPINNED vs PyBullet."""
+import numpy as np
+import pytest
+
+from tests import parity_util as P
+from tests.scenarios import coil_pipe_flat
+
+pytestmark = pytest.mark.gpu
+
+POS = P.POS
+REST = np.array([0, -0.215, -np.pi / 3, -2.57, 0, 2.356, 2.356, 0, 0])
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch
+
+
+def _check_defaults(g):
+    c = g.cfg
+    assert abs(c.residual_threshold - 1e-7) < 1e-12 and abs(c.warmstart - 0.85) < 1e-6 and c.exit_check_stride == 16 and c.solver_iters == 50
+
+
+@pytest.mark.parametrize("N,steps,solver_path", [(4096, 170, 0), (512, 170, 1)])
+def test_defaults_one_step_parity(torch_mod, oracle_mod, N, steps, solver_path):
+    """BASELINE configs[2] size (4096 envs) at the library defaults, every step from reset through free fall (where the exit test fires
+    after 20-49 iterations), landing and contact steady state; and the same at 512 envs with the DOF-space solver forced (its exit test
+    reads bit 32 of the ballot)."""
+    g = P.GpuProduct(N, seed=5, solver_path=solver_path)
+    _check_defaults(g)
+
+    def variants_ok(v):
+        vc = np.bincount(v, minlength=6)
+        if solver_path == 0:      # one row per lane (with / without the arm limit rows) and two rows per lane all ran; no DOF space below 33 contacts
+            assert vc[1] + vc[2] > 0.3 * len(v) and vc[5] > 100 and vc[0] == 0, vc
+        else:
+            assert vc[0] == len(v), vc
+    P.defaults_one_step_check("HIP defaults N=%d solver_path=%d" % (N, solver_path), oracle_mod, g, N, steps, expect_variants=variants_ok)
+
+
+def test_defaults_heavy_contact_variants(torch_mod, oracle_mod):
+    """11..32 contacts (two rows per lane) and > 32 contacts (DOF space with the global-scratch spill) at the defaults: pipes coiled
+    flat on the table (25 table + up to ~17 self contacts) under a hovering arm, warm start live, resynchronised every step."""
+    N = 16
+    A = oracle_mod.Oracle(N, seed=2); B = oracle_mod.Oracle(N, seed=2, exit_check_stride=16); led = P.ConditionedParity(oracle_mod, slots=64)
+    g = P.GpuProduct(N, seed=2)
+    _check_defaults(g)
+    A.set_state(coil_pipe_flat(A.get_state()))
+    p0, _ = oracle_mod.fk_arm(REST, 9)
+    a = np.tile([p0[0], p0[1], p0[2], 0.0], (N, 1))
+    perr, nc, dB, variants = [], [], [], []
+    for t in range(240):
+        P.sync_product(g, A); P.sync_oracle(B, A); led.before(A)
+        A.step(a); B.step(a); g.step(a)
+        sa = A.get_state(); sg = g.get_state()
+        np.testing.assert_array_equal(A.ncontacts(), sg[:, 106].astype(int))
+        perr.append(np.abs(sa[:, POS] - sg[:, POS]).max(1)); nc.append(A.ncontacts().copy())
+        cf = A.contact_force(); led.after(A, a, perr[-1], np.abs(sg[:, 105] - cf) / (1 + np.abs(cf)))
+        dB.append(sg[:, 107].astype(int) - B.pgs_iters()); variants.append(sg[:, 114].astype(int))
+    perr, nc, dB, variants = map(np.concatenate, (perr, nc, dB, variants))
+    two, dof = variants == 5, variants == 0
+    print("defaults, heavy envs: contacts min/max %d / %d; two-rows-per-lane %d env-steps (pose max %.2e), DOF-space > 32 contacts %d env-steps (pose max %.2e); iteration mismatches vs same-cadence oracle %d" % (
+        nc.min(), nc.max(), two.sum(), perr[two].max() if two.any() else 0, dof.sum(), perr[dof].max() if dof.any() else 0, (dB != 0).sum()))
+    assert two.sum() > 300 and dof.sum() > 300 and np.array_equal(dof, nc > 32)
+    led.finish("HIP defaults, 25..48 contacts")
+    assert (dB != 0).mean() < 1e-2
+
+
+@pytest.mark.parametrize("bent", [False, True])
+def test_defaults_trajectory_1000_steps(torch_mod, oracle_mod, bent):
+    """north_star: 1000 steps from identical seeds WITHOUT resynchronisation, library defaults on both sides (oracle at Bullet's
+    cadence): peg-tip pose <= 1e-3 m, contact-normal force <= 1e-2 N (16-step mean: contacts of the creeping bent pipe make / break
+    one step apart in the two simulations, which shows as single-step force jitter), obs <= 1e-3."""
+    torch = torch_mod
+    N = 8
+    from peg_in_hole_gym_amd.vec_env import PihVecEnv
+    o = oracle_mod.Oracle(N); g = PihVecEnv(N)
+    _check_defaults(g)
+    p0, _ = oracle_mod.fk_arm(REST, 9)
+    if bent:
+        a = np.tile([p0[0], p0[1], p0[2], 0.0], (N, 1))
+        for _ in range(1000):
+            o.step(a)
+        s = o.get_state(); s[:, 25:31] = 0; s[:, 54:77] = 0; o.set_state(s)
+    else:
+        s = o.get_state(); s[:, 31:54] = 0; s[:, 20] = -0.04 + 1e-4; o.set_state(s)
+    st = g.state().cpu().numpy().astype(np.float64); st[:, :98] = s[:, :98]; st[:, 128] = 0
+    g.set_state(torch.tensor(st, dtype=torch.float32))
+    maxd = maxo = 0.0
+    fo, fg = [], []
+    for t in range(1000):
+        ph = 2 * np.pi * t / 500.0
+        a = np.tile([p0[0] + 0.1 * np.sin(ph), p0[1] + 0.1 * np.cos(ph) - 0.1, p0[2] + 0.05 * np.sin(2 * ph), 0.02], (N, 1))
+        oo, _, _ = o.step(a)
+        og, _, _ = g.step(torch.tensor(a, dtype=torch.float32))
+        maxd = max(maxd, np.abs(o.tip_pose()[:, :3] - g.tip_pose().cpu().numpy()[:, :3]).max())
+        maxo = max(maxo, np.abs(oo - og.cpu().numpy()).max())
+        fo.append(o.contact_force()); fg.append(g.contact_force().cpu().numpy().astype(np.float64))
+    fo, fg = np.array(fo), np.array(fg)
+    f_avg, f_inst, f_calm, calm_share = P.force_parity(fo, fg)
+    print("defaults trajectory bent=%s: tip %.3e m, force 16-step mean %.3e N, instantaneous %.3e N (%.3e N on the %.1f %% of steps away from force transients), obs %.3e" % (
+        bent, maxd, f_avg, f_inst, f_calm, 100 * calm_share, maxo))
+    assert maxd < 1e-3 and maxo < 1e-3 and f_avg < 1e-2, (maxd, maxo, f_avg)
+    assert f_calm < 1e-2, "instantaneous contact force differs by %.3e N on a step without a force transient" % f_calm
+    assert f_inst < 5e-2, "single-step force difference at a load / unload transient %.3e N" % f_inst
+    assert calm_share > 0.9

@@ -38,14 +38,18 @@ def test_fly_reset_and_state_roundtrip(torch_mod, oracle_mod):
     s3 = g.state().cpu()
     assert torch.equal(s3[mask == 0], s2[mask == 0]) and (s3[mask == 1][:, 33] > s2[mask == 1][:, 33]).all()
     g.reset(hard_reset=True)
-    np.testing.assert_array_equal(g.state().cpu().numpy(), sg)   # hard reset replays the seed's first scene bit for bit
+    s4 = g.state().cpu()
+    assert not torch.equal(s4[:, 18:21], torch.tensor(sg)[:, 18:21]) and (s4[:, 33] > s3[:, 33]).all()   # hard reset: a NEW scene (draw counter advances)
+    g.reset(hard_reset=True, seed=int(g.cfg.seed))
+    np.testing.assert_array_equal(g.state().cpu().numpy(), sg)   # explicit replay (seed != 0): the seed's first scene bit for bit
 
 
 @pytest.mark.parametrize("N,steps", [(4096, 200), (70, 400)])
 def test_fly_one_step_parity_resynchronised(torch_mod, oracle_mod, N, steps):
     """Random-action episodes with auto-reset (throws, arm swings, arm-object and object-table contacts, landings, catches), the GPU
-    state overwritten with the oracle's before every step.  done / reward / contact counts must be equal; state error percentiles
-    asserted; the number of contact env-steps the run covered is asserted."""
+    state overwritten with the oracle's before every step.  An env-step whose done flag, reward or contact count differs from the oracle's
+    took another DISCRETE branch (the object within float rounding of a contact / catch / landing threshold): those are counted and their
+    share is bounded (5e-5); on every other env-step pose, velocity (max, not only percentiles) and force errors are asserted."""
     torch = torch_mod
     kw = dict(seed=7, dt=DT, residual_threshold=0.0, auto_reset=1, max_episode_steps=150)
     o = oracle_mod.FlyOracle(N, omp=N > 256, **kw); g = _gpu(N, debug=1 if N <= 256 else 0, **kw)
@@ -60,7 +64,6 @@ def test_fly_one_step_parity_resynchronised(torch_mod, oracle_mod, N, steps):
         # an env whose object passes within float rounding of a contact / catch / landing threshold, or whose sphere is equally deep
         # in two neighbouring capsules, takes a different discrete branch than the oracle: counted, bounded, and left out of the stats
         same = (do == dg.cpu().numpy()) & (so[:, 44] == sg[:, 44]) & (ro == rg.cpu().numpy())
-        same &= np.abs(so[:, [*range(6, 12), *range(25, 31)]] - sg[:, [*range(6, 12), *range(25, 31)]]).max(1) < 0.05
         mism += int((~same).sum())
         ncs += int(so[:, 44].sum()); nrew += int(ro.sum())
         perr.append(np.abs(so[same][:, [*range(0, 6), *range(18, 25)]] - sg[same][:, [*range(0, 6), *range(18, 25)]]).max(1))
@@ -72,7 +75,7 @@ def test_fly_one_step_parity_resynchronised(torch_mod, oracle_mod, N, steps):
         N, N * steps, ncs, nrew, mism, np.percentile(perr, 50), np.percentile(perr, 99), perr.max(), np.percentile(verr, 50), np.percentile(verr, 99), verr.max(), np.percentile(ferr, 99)))
     assert ncs > (20000 if N > 256 else 500) and mism <= 5e-5 * N * steps + 2
     assert np.percentile(perr, 50) < 2e-6 and np.percentile(perr, 99) < 2e-5 and perr.max() < 1e-3
-    assert np.percentile(verr, 50) < 1e-4 and np.percentile(verr, 99) < 5e-3
+    assert np.percentile(verr, 50) < 1e-4 and np.percentile(verr, 99) < 5e-3 and verr.max() < 0.05      # every env-step that took the oracle's branch
     assert np.percentile(ferr, 99) < 1e-2
 
 

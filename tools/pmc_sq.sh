@@ -1,9 +1,11 @@
 #!/bin/bash
 # Issue-slot accounting of pih_step_kernel from the SQ counters (own --pmc passes, no other trace domain):
 #   WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~= WAVE_CYCLES (MI355X_MICROARCH.md, PMC slots); counts are quad-cycles.
-# Usage (GPU box, repo root):  bash tools/pmc_sq.sh <tag>   -> gpurun_out/sq_<tag>.json
+# Usage (GPU box, repo root):  bash tools/pmc_sq.sh <tag> [peg-in-hole|random-fly]   -> gpurun_out/sq_<tag>[_fly].json
 set -e
 TAG=${1:-latest}
+TASK=${2:-peg-in-hole}
+SUF=""; [ "$TASK" = "random-fly" ] && SUF="_fly"
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU"
@@ -13,17 +15,24 @@ P3="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_V
 i=0
 for C in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  rm -rf $R/gpurun_out/sq_${TAG}_$i
-  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/sq_${TAG}_$i -- python $R/bench.py --steps 40 --warmup 20 --no-cpu-baseline > $R/gpurun_out/sq_${TAG}_$i.bench.json 2> $R/gpurun_out/sq_${TAG}_$i.err
+  rm -rf $R/gpurun_out/sq_${TAG}${SUF}_$i
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/sq_${TAG}${SUF}_$i -- python $R/bench.py --task $TASK --steps 40 --warmup 20 --no-cpu-baseline > $R/gpurun_out/sq_${TAG}${SUF}_$i.bench.json 2> $R/gpurun_out/sq_${TAG}${SUF}_$i.err
 done
-cd $R && python - "$TAG" <<'PY'
+cd $R && python - "$TAG" "$TASK" <<'PY'
 import csv, glob, json, os, sys
-tag = sys.argv[1]
-out = {"tag": tag, "kernel": "pih_step_kernel", "units": "per launch (SQ cycle counters are quad-cycles summed over waves)"}
+sys.path.insert(0, os.getcwd())
+from tools.source_hash import source_sha16
+tag, task = sys.argv[1], sys.argv[2]
+fly = task == "random-fly"
+suf, kernel = ("_fly", "pih_fly_step_kernel") if fly else ("", "pih_step_kernel")
+# resident waves per SIMD while the kernel runs: peg-in-hole 2 (255 VGPR, 8 one-wave workgroups per CU); random-fly: the launch has fewer
+# waves than SIMDs, so at most 1
+out = {"tag": tag, "task": task, "kernel": kernel, "units": "per launch (SQ cycle counters are quad-cycles summed over waves)", "source_sha16": source_sha16(),
+       "waves_per_simd": 1 if fly else 2}
 acc = {}
-for f in glob.glob("gpurun_out/sq_%s_*/**/*counter_collection.csv" % tag, recursive=True):
+for f in glob.glob("gpurun_out/sq_%s%s_[0-9]/**/*counter_collection.csv" % (tag, suf), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "pih_step_kernel" in r["Kernel_Name"]:
+        if kernel in r["Kernel_Name"]:
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     out[k] = sum(v) / len(v)
@@ -37,6 +46,6 @@ if w:
     for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_LDS"):
         if k in out:
             out["frac_" + k] = out[k] / w
-json.dump(out, open("gpurun_out/sq_%s.json" % tag, "w"), indent=1)
+json.dump(out, open("gpurun_out/sq_%s%s.json" % (tag, suf), "w"), indent=1)
 print(json.dumps(out))
 PY
