@@ -45,6 +45,19 @@ def test_config_struct_layout_matches_header(tmp_path):
     assert c.exit_check_stride == 16 and abs(c.residual_threshold - 1e-7) < 1e-12 and abs(c.warmstart - 0.85) < 1e-6
 
 
+def test_integration_md_stub_matches_the_abi():
+    """The ctypes stub printed in INTEGRATION.md section 1 (executed verbatim on the GPU by tests/test_gpu_api.py) must describe the
+    CURRENT ABI: same struct fields in the same order as _lib.PihConfig, the current version number, pih_reset with its seed argument."""
+    import re
+    from peg_in_hole_gym_amd import _lib
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# peg_in_hole_gym/envs/_pih\.py.*?)```", md, re.S).group(1)
+    fields = re.findall(r'\("([a-z_0-9]+)", C\.', code)
+    assert fields == [f[0] for f in _lib.PihConfig._fields_]
+    assert "pih_abi_version() == %d" % _lib.ABI_VERSION in code
+    assert re.search(r"pih_reset\(h, None, int\(hard_reset\), C\.c_uint64\(0\), stream\)", code)
+
+
 def test_create_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
