@@ -112,7 +112,8 @@ typedef struct pih_config {
                                  the last one (an env that meets the threshold between two tests runs at most s - 1 further iterations, each of
                                  whose row updates is below the threshold).  Default 16; the oracle has the same switch, tests/test_gpu_defaults.py
                                  bounds the difference against Bullet's cadence; bench.py reports the value it ran with */
-  int32_t reserved_i;
+  int32_t object_id;          /* random-fly: which free-flying object (index into PIH_FLY_OBJ_NAMES of include/pih_model.h, generated from the
+                                 reference's asset files; args[0] of README.md:38): 0 'Banana', 1 'Amicelli' */
   uint64_t seed;
   float dt;                   /* 1/240 */
   float residual_threshold;   /* 1e-7 */
@@ -132,6 +133,8 @@ void pih_default_config(pih_config* cfg);
 int pih_abi_version(void);
 /* per-task sizes of the tensors the caller owns: out[0] = action dim, out[1] = obs dim, out[2] = state words per env */
 int pih_task_dims(int task_id, int32_t out[3]);
+/* name of object `object_id` of a task (random-fly: the free-flying objects compiled in from envs/assets/urdf), NULL past the end */
+const char* pih_object_name(int task_id, int object_id);
 /* offsets_host: HOST float[n_envs,3] (envs/base_env.py:35-55 placement) or NULL for zeros */
 int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** out);
 int pih_destroy(pih_handle* h);

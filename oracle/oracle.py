@@ -18,7 +18,7 @@ def _config_type(real):
     class _Config(C.Structure):
         _fields_ = [("n_envs", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32), ("ik_iters", C.c_int32),
                     ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("enable_self_collision", C.c_int32),
-                    ("env_index0", C.c_int32), ("attach_ball", C.c_int32), ("enable_arm_collision", C.c_int32), ("exit_check_stride", C.c_int32), ("reserved_i", C.c_int32), ("seed", C.c_uint64), ("dt", real), ("residual_threshold", real),
+                    ("env_index0", C.c_int32), ("attach_ball", C.c_int32), ("enable_arm_collision", C.c_int32), ("exit_check_stride", C.c_int32), ("object_id", C.c_int32), ("seed", C.c_uint64), ("dt", real), ("residual_threshold", real),
                     ("erp", real), ("warmstart", real), ("contact_margin", real), ("linear_slop", real),
                     ("ik_damping", real), ("ik_residual", real), ("dv", real)]
     return _Config
@@ -284,6 +284,8 @@ def _fly_protos(L):
     L.piho_fly_arm_kinetic_energy.argtypes = [dp, dp]
     L.piho_fly_arm_kinetic_energy.restype = C.c_float if L._np_real is np.float32 else C.c_double
     L.piho_fly_random_pos.argtypes = [C.c_uint64, C.c_uint64, dp]
+    L.piho_fly_object_name.argtypes = [C.c_int]; L.piho_fly_object_name.restype = C.c_char_p
+    L.piho_fly_num_contact_slots.restype = C.c_int
     L._fly_ready = True
     return L
 
@@ -333,10 +335,20 @@ class FlyOracle:
         self.L.piho_debug_contacts_all(self.h, _dp(out), cnt.ctypes.data_as(C.POINTER(C.c_int32))); return out, cnt
 
     def debug_contacts(self, env=0):
-        out = np.zeros((10, 10), self.real); self.L.piho_fly_debug_contacts(self.h, env, _dp(out)); return out
+        out = np.zeros((self.L.piho_fly_num_contact_slots(), 10), self.real); self.L.piho_fly_debug_contacts(self.h, env, _dp(out)); return out
 
     def debug_udot(self, env=0):
         out = np.zeros(12, self.real); self.L.piho_fly_debug_udot(self.h, env, _dp(out)); return out
+
+
+def fly_object_names():
+    """names of the free-flying objects compiled into the oracle (= PIH_FLY_OBJ_NAMES of include/pih_model.h), index = object_id"""
+    L = _fly_protos(lib()); out = []
+    while True:
+        n = L.piho_fly_object_name(len(out))
+        if n is None:
+            return out
+        out.append(n.decode())
 
 
 def fly_mass_matrix(q):

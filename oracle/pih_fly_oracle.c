@@ -15,8 +15,10 @@
 
 #define FNJ 6
 #define FND 12                  /* 6 arm joints + object (lin 3, ang 3) */
-#define FNS PIH_FLY_OBJ_NSPH
-#define FNC (2 * FNS)           /* contact slots: sphere s vs its deepest arm capsule (slot s), sphere s vs the table (slot FNS + s) */
+#define FNS PIH_FLY_OBJ_MAXSPH  /* object spheres (padded; object o uses the first FO_NSPH[o]) */
+#define FNA 5                   /* arm-vs-table slots: the deeper capsule end of links 1..5 (link 0, the shoulder, cannot reach the table) */
+#define FNC (2 * FNS + FNA)     /* contact slots: sphere s vs its deepest arm capsule (slot s), sphere s vs the table (slot FNS + s), arm link 1 + a vs the
+                                   table (slot 2 FNS + a; linkA = the arm link, no object part) */
 #define FROWS (3 * FNJ + FNC)
 
 static const real U5_RFIX[6][9] = PIH_UR5_RFIX;
@@ -36,9 +38,13 @@ static const real U5_CAP_A[6][3] = PIH_UR5_CAP_A;
 static const real U5_CAP_B[6][3] = PIH_UR5_CAP_B;
 static const real U5_CAP_R[6] = PIH_UR5_CAP_R;
 static const real U5_REST[6] = PIH_UR5_REST;
-static const real FO_INERTIA[3] = PIH_FLY_OBJ_INERTIA;
-static const real FO_SPH_C[FNS][3] = PIH_FLY_OBJ_SPH_C;
-static const real FO_SPH_R[FNS] = PIH_FLY_OBJ_SPH_R;
+static const real FO_MASS[PIH_FLY_NOBJ] = PIH_FLY_OBJ_MASS;
+static const real FO_INERTIA_T[PIH_FLY_NOBJ][3] = PIH_FLY_OBJ_INERTIA;
+static const int FO_NSPH[PIH_FLY_NOBJ] = PIH_FLY_OBJ_NSPH;
+static const real FO_SPH_C_T[PIH_FLY_NOBJ][FNS][3] = PIH_FLY_OBJ_SPH_C;
+static const real FO_SPH_R_T[PIH_FLY_NOBJ][FNS] = PIH_FLY_OBJ_SPH_R;
+static const char* const FO_NAMES[PIH_FLY_NOBJ] = PIH_FLY_OBJ_NAMES;
+static int fly_object(const piho_config* c) { return c->object_id >= 0 && c->object_id < PIH_FLY_NOBJ ? c->object_id : 0; }
 
 typedef struct { real R[9]; v3 o, c, a; real Iw[9]; } FLink;
 typedef struct { int valid, link; v3 p, n; real depth, lambda; } FContact;
@@ -165,9 +171,12 @@ static void fly_reset_env(piho_fly_handle* h, int e) {
  * FNS + s = sphere s against the table plane.  Normal points from the other body to the object. */
 static void fly_collide(const piho_config* c, FEnv* E, const FLink* K) {
   const real* s = E->s;
+  const int ob = fly_object(c);
+  const real (*FO_SPH_C)[3] = FO_SPH_C_T[ob]; const real* FO_SPH_R = FO_SPH_R_T[ob];
   real Ro[9]; q_to_m(Ro, &s[PIHO_F_OQUAT]);
   E->ncontacts = 0; E->landed = 0;
-  for (int i = 0; i < FNS; i++) {
+  for (int k = 0; k < FNC; k++) { E->contacts[k].valid = 0; E->contacts[k].lambda = 0; }
+  for (int i = 0; i < FO_NSPH[ob]; i++) {
     v3 cw; m_mulv(cw, Ro, FO_SPH_C[i]); v_add(cw, cw, &s[PIHO_F_OPOS]);
     FContact* ca = &E->contacts[i]; ca->valid = 0; ca->lambda = 0;
     real best = 1e30;
@@ -192,6 +201,21 @@ static void fly_collide(const piho_config* c, FEnv* E, const FLink* K) {
       v_set(ct->p, cw[0], cw[1], cw[2] - FO_SPH_R[i] - 0.5 * depth);
     }
     E->ncontacts += ca->valid + ct->valid;
+  }
+  /* UR5 vs the table top (envs/assets/meshes/ur5/collision/<link>.stl -> the capsules of include/pih_model.h): per link 1..5 the DEEPER of the
+   * capsule's two end spheres against the plane z = PIH_TABLE_Z (ties: end A).  Normal rows only (BUILD-DEFINED: the links carry no
+   * <contact> block, pybullet's default lateral friction would add two friction rows per contact). */
+  for (int a = 0; a < FNA; a++) {
+    const int L = 1 + a;
+    FContact* ct = &E->contacts[2 * FNS + a]; ct->valid = 0; ct->lambda = 0;
+    v3 pa, pb; m_mulv(pa, K[L].R, U5_CAP_A[L]); v_add(pa, pa, K[L].o); m_mulv(pb, K[L].R, U5_CAP_B[L]); v_add(pb, pb, K[L].o);
+    const real* pe = pb[2] < pa[2] ? pb : pa;
+    real depth = pe[2] - PIH_TABLE_Z - U5_CAP_R[L];
+    if (depth < c->contact_margin) {
+      ct->valid = 1; ct->link = L; ct->depth = depth; v_set(ct->n, 0, 0, 1);
+      v_set(ct->p, pe[0], pe[1], pe[2] - U5_CAP_R[L] - 0.5 * depth);
+      E->ncontacts += 1;
+    }
   }
 }
 
@@ -223,6 +247,8 @@ static void fly_step_env(piho_fly_handle* h, int e, const real* action, real* ob
   for (int i = 0; i < FNJ; i++) ud[i] = -bias[i];
   chol_solve(M, FNJ, FNJ, ud);
   real Ro[9], Iw[9], Iwi[9];
+  const int ob = fly_object(c);
+  const real* FO_INERTIA = FO_INERTIA_T[ob]; const real fo_mass = FO_MASS[ob];
   q_to_m(Ro, &s[PIHO_F_OQUAT]);
   for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) {
     real a = 0, b = 0;
@@ -230,7 +256,7 @@ static void fly_step_env(piho_fly_handle* h, int e, const real* action, real* ob
     Iw[3 * r + cc] = a; Iwi[3 * r + cc] = b;
   }
   {
-    const real m = PIH_FLY_OBJ_MASS;
+    const real m = fo_mass;
     v3 v = {u[6], u[7], u[8]}, w = {u[9], u[10], u[11]}, Iwv, t, nn;
     real sv = LIN_DAMP + LIN_DAMP * v_norm(v), sw = ANG_DAMP + ANG_DAMP * v_norm(w);
     ud[6] = -sv * v[0]; ud[7] = -sv * v[1]; ud[8] = PIH_GRAVITY_Z - sv * v[2];
@@ -266,6 +292,18 @@ static void fly_step_env(piho_fly_handle* h, int e, const real* action, real* ob
     const FContact* ct = &E->contacts[k];
     if (!ct->valid) continue;
     FRow* r = &rows[nr]; memset(r, 0, sizeof *r); crow[k] = nr++;
+    if (k >= 2 * FNS) {
+      /* arm link vs the table: linkA = the arm link (the normal points from the table to the arm), no object part */
+      for (int L = 0; L <= ct->link; L++) { v3 rr, tt; v_sub(rr, ct->p, K[L].o); v_cross(tt, K[L].a, rr); r->J[L] = v_dot(ct->n, tt); }
+      real wa[FNJ]; for (int i = 0; i < FNJ; i++) wa[i] = r->J[i];
+      chol_solve(M, FNJ, FNJ, wa);
+      real jw = 0, ju = 0; for (int i = 0; i < FNJ; i++) { r->W[i] = wa[i]; jw += r->J[i] * wa[i]; ju += r->J[i] * u[i]; }
+      r->dinv = 1 / jw;
+      real pen = ct->depth + c->linear_slop;
+      real vb = pen > 0 ? -pen / dt : -c->erp * pen / dt;     /* Bullet's default contact ERP for the arm (no <contact> block in ur5.urdf) */
+      r->rhs = (vb - ju) * r->dinv; r->lo = 0; r->hi = 1e30;
+      continue;
+    }
     v3 ro, t; v_sub(ro, ct->p, &s[PIHO_F_OPOS]); v_cross(t, ro, ct->n);
     for (int i = 0; i < 3; i++) { r->J[6 + i] = ct->n[i]; r->J[9 + i] = t[i]; }
     for (int L = 0; L <= ct->link; L++) { v3 rr, tt; v_sub(rr, ct->p, K[L].o); v_cross(tt, K[L].a, rr); r->J[L] = -v_dot(ct->n, tt); }
@@ -273,7 +311,7 @@ static void fly_step_env(piho_fly_handle* h, int e, const real* action, real* ob
     chol_solve(M, FNJ, FNJ, wa);
     for (int i = 0; i < FNJ; i++) r->W[i] = wa[i];
     v3 wt; m_mulv(wt, Iwi, t);
-    for (int i = 0; i < 3; i++) { r->W[6 + i] = ct->n[i] / PIH_FLY_OBJ_MASS; r->W[9 + i] = wt[i]; }
+    for (int i = 0; i < 3; i++) { r->W[6 + i] = ct->n[i] / fo_mass; r->W[9 + i] = wt[i]; }
     real jw = 0, ju = 0; for (int i = 0; i < FND; i++) { jw += r->J[i] * r->W[i]; ju += r->J[i] * u[i]; }
     r->dinv = 1 / jw;
     real pen = ct->depth + c->linear_slop;
@@ -402,3 +440,5 @@ real piho_fly_arm_kinetic_energy(const real q[6], const real qd[6]) {
   return T;
 }
 void piho_fly_random_pos(uint64_t seed, uint64_t ctr, real out[3]) { fly_random_pos(seed, &ctr, out); }
+const char* piho_fly_object_name(int object_id) { return object_id >= 0 && object_id < PIH_FLY_NOBJ ? FO_NAMES[object_id] : NULL; }
+int piho_fly_num_contact_slots(void) { return FNC; }

@@ -51,7 +51,7 @@ typedef struct {
   int32_t enable_arm_collision; /* arm collision spheres (pih_model.h PIH_ARM_SPH_*): bit 0 vs the table plane, bit 1 vs the pipe; default 3 */
   int32_t exit_check_stride;  /* cadence of the PGS early-exit test: 1 (default) = after every iteration, as Bullet does; s > 1 = the product's
                                  sampled cadence (include/pih.h pih_config.exit_check_stride): iterations 1..4, then 4 + s k, and the last one */
-  int32_t reserved_i;
+  int32_t object_id;          /* random-fly: index of the free-flying object (PIH_FLY_OBJ_NAMES, include/pih_model.h) */
   uint64_t seed;
   piho_real dt;                  /* 1/240 */
   piho_real residual_threshold;  /* 1e-7 (squared velocity residual), 0 = never exit early */
@@ -137,7 +137,9 @@ void piho_fly_get_pgs_iters(const piho_fly_handle* h, int32_t* out);
 void piho_fly_step(piho_fly_handle* h, const piho_real* actions, piho_real* obs, piho_real* reward, uint8_t* done);
 void piho_fly_get_state(const piho_fly_handle* h, piho_real* out /* [n,48] */);
 void piho_fly_set_state(piho_fly_handle* h, const piho_real* in);
-void piho_fly_debug_contacts(const piho_fly_handle* h, int env, piho_real* out /* [10,10]: valid link p n depth lambda_n per slot */);
+void piho_fly_debug_contacts(const piho_fly_handle* h, int env, piho_real* out /* [slots,10]: valid link p n depth lambda_n per slot; slots = piho_fly_num_contact_slots() */);
+int piho_fly_num_contact_slots(void);    /* 2 x PIH_FLY_OBJ_MAXSPH (object sphere vs arm, vs table) + 5 (arm links 1..5 vs table) */
+const char* piho_fly_object_name(int object_id);   /* PIH_FLY_OBJ_NAMES[object_id], NULL past the end */
 void piho_fly_debug_udot(const piho_fly_handle* h, int env, piho_real* out /* [12] */);
 void piho_fly_mass_matrix(const piho_real q[6], piho_real M[36]);
 piho_real piho_fly_arm_kinetic_energy(const piho_real q[6], const piho_real qd[6]);

@@ -18,7 +18,7 @@ S_SPARE, S_TIP, S_CFORCE, S_NCONTACT, S_PGS_ITERS, S_INVALID, S_CACHE_N = 97, 98
 TASK_PEG_IN_HOLE, TASK_RANDOM_FLY = 0, 1
 ABI_VERSION = 4
 
-EXPORTS = ["pih_default_config", "pih_abi_version", "pih_task_dims", "pih_create", "pih_destroy", "pih_reset", "pih_reseed", "pih_step", "pih_step_n",
+EXPORTS = ["pih_default_config", "pih_abi_version", "pih_task_dims", "pih_object_name", "pih_create", "pih_destroy", "pih_reset", "pih_reseed", "pih_step", "pih_step_n",
            "pih_get_state", "pih_set_state", "pih_ik", "pih_ik_ur5", "pih_render", "pih_render_ex", "pih_grasp_labels", "pih_timing", "pih_timing2", "pih_set_timing", "pih_last_error"]
 
 
@@ -26,7 +26,7 @@ class PihConfig(C.Structure):
     """struct pih_config (include/pih.h)"""
     _fields_ = [("n_envs", C.c_int32), ("env_index0", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32),
                 ("ik_iters", C.c_int32), ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32),
-                ("enable_self_collision", C.c_int32), ("debug", C.c_int32), ("schedule", C.c_int32), ("enable_arm_collision", C.c_int32), ("task_id", C.c_int32), ("solver_path", C.c_int32), ("attach_ball", C.c_int32), ("exit_check_stride", C.c_int32), ("reserved_i", C.c_int32), ("seed", C.c_uint64),
+                ("enable_self_collision", C.c_int32), ("debug", C.c_int32), ("schedule", C.c_int32), ("enable_arm_collision", C.c_int32), ("task_id", C.c_int32), ("solver_path", C.c_int32), ("attach_ball", C.c_int32), ("exit_check_stride", C.c_int32), ("object_id", C.c_int32), ("seed", C.c_uint64),
                 ("dt", C.c_float), ("residual_threshold", C.c_float), ("erp", C.c_float), ("warmstart", C.c_float),
                 ("contact_margin", C.c_float), ("linear_slop", C.c_float), ("ik_damping", C.c_float), ("ik_residual", C.c_float),
                 ("dv", C.c_float), ("reserved_f", C.c_float * 3)]
@@ -56,6 +56,8 @@ def load():
     L.pih_default_config.restype = None
     L.pih_abi_version.restype = C.c_int
     L.pih_task_dims.argtypes = [C.c_int, C.POINTER(C.c_int32 * 3)]
+    L.pih_object_name.argtypes = [C.c_int, C.c_int]
+    L.pih_object_name.restype = C.c_char_p
     L.pih_create.argtypes = [C.POINTER(PihConfig), vp, C.POINTER(vp)]
     L.pih_destroy.argtypes = [vp]
     L.pih_reset.argtypes = [vp, vp, C.c_int, C.c_uint64, vp]
@@ -92,6 +94,16 @@ def task_dims(task_id):
     if load().pih_task_dims(int(task_id), C.byref(out)) != 0:
         raise PihError("unknown task_id %r" % (task_id,))
     return int(out[0]), int(out[1]), int(out[2])
+
+
+def object_names(task_id):
+    """names of the objects compiled into the library for a task (random-fly: generated from the reference's asset files), index = object_id"""
+    L = load(); out = []
+    while True:
+        n = L.pih_object_name(int(task_id), len(out))
+        if n is None:
+            return out
+        out.append(n.decode())
 
 
 def default_config(**kw):

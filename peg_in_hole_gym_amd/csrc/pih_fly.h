@@ -23,7 +23,9 @@
 namespace pih {
 namespace fly {
 
-constexpr int NJ = 6, FND = 12, NS = PIH_FLY_OBJ_NSPH, NC = 2 * NS;
+constexpr int NJ = 6, FND = 12, NS = PIH_FLY_OBJ_MAXSPH;   // object spheres, padded (object o uses the first O_NSPH[o])
+constexpr int NA = 5;                                       // arm-vs-table slots: links 1..5 (the shoulder cannot reach the table)
+constexpr int NC = 2 * NS + NA;    // contact slots: sphere s vs its deepest arm capsule, sphere s vs the table, arm link 1 + a vs the table
 constexpr int SW = PIH_FLY_STATE_WORDS;
 constexpr int CW = 24;             // words of one contact row record in lane memory
 constexpr int LANE_WORDS = NC * CW;
@@ -39,9 +41,12 @@ PIH_CONST real U_CAP_A[NJ][3] = PIH_UR5_CAP_A;
 PIH_CONST real U_CAP_B[NJ][3] = PIH_UR5_CAP_B;
 PIH_CONST real U_CAP_R[NJ] = PIH_UR5_CAP_R;
 PIH_CONST real U_REST[NJ] = PIH_UR5_REST;
-PIH_CONST real O_INERTIA[3] = PIH_FLY_OBJ_INERTIA;
-PIH_CONST real O_SPH_C[NS][3] = PIH_FLY_OBJ_SPH_C;
-PIH_CONST real O_SPH_R[NS] = PIH_FLY_OBJ_SPH_R;
+// free-flying objects, generated from the reference's asset files (tools/gen_model_header.py); object id = pih_config.object_id
+PIH_CONST real O_MASS[PIH_FLY_NOBJ] = PIH_FLY_OBJ_MASS;
+PIH_CONST real O_INERTIA[PIH_FLY_NOBJ][3] = PIH_FLY_OBJ_INERTIA;
+PIH_CONST int O_NSPH[PIH_FLY_NOBJ] = PIH_FLY_OBJ_NSPH;
+PIH_CONST real O_SPH_C[PIH_FLY_NOBJ][NS][3] = PIH_FLY_OBJ_SPH_C;
+PIH_CONST real O_SPH_R[PIH_FLY_NOBJ][NS] = PIH_FLY_OBJ_SPH_R;
 
 // per-lane scratch: word w of this lane lives at p[w * stride] (GPU: LDS, stride 64; host emulation: a plain array, stride 1)
 struct LaneMem {
@@ -135,9 +140,13 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
     Q4 oq; oq.x = S[PIH_F_OQUAT]; oq.y = S[PIH_F_OQUAT + 1]; oq.z = S[PIH_F_OQUAT + 2]; oq.w = S[PIH_F_OQUAT + 3];
     const M3 Ro = q_to_m(oq);
     const V3 op = ld3(S + PIH_F_OPOS);
-    V3 sc[NS];
+    const int ob = P.object, nsph = O_NSPH[ob];      // wave-uniform: scalar loads from the object table
+    const real omass_inv = (real)1 / O_MASS[ob];
+    V3 sc[NS]; real srad[NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++) sc[i] = op + mul(Ro, ld3(O_SPH_C[i]));
+    for (int i = 0; i < NS; i++) { sc[i] = op + mul(Ro, ld3(O_SPH_C[ob][i])); srad[i] = O_SPH_R[ob][i]; }
+    // arm-vs-table candidates (links 1..5): the deeper capsule end against the plane z = PIH_TABLE_Z
+    real adepth[NA]; V3 apt[NA];
     // contact candidates of slot i (sphere i vs its deepest capsule): depth, link, normal, point
     real cdepth[NS]; int clink[NS]; V3 cn[NS], cp[NS];
 #pragma unroll
@@ -176,10 +185,15 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
           const V3 ac = sc[i] - A0;
           const real t = l2 > (real)1e-18 ? clampr(dot(ac, ab) / l2, 0, 1) : (real)0;
           const V3 d = sc[i] - (A0 + t * ab);
-          const real dist = norm(d), depth = dist - O_SPH_R[i] - U_CAP_R[L];
-          if (depth < P.margin && depth < cdepth[i] && dist > (real)1e-9) {
-            cdepth[i] = depth; clink[i] = L; cn[i] = ((real)1 / dist) * d; cp[i] = sc[i] - (O_SPH_R[i] + (real)0.5 * depth) * cn[i];
+          const real dist = norm(d), depth = dist - srad[i] - U_CAP_R[L];
+          if (i < nsph && depth < P.margin && depth < cdepth[i] && dist > (real)1e-9) {
+            cdepth[i] = depth; clink[i] = L; cn[i] = ((real)1 / dist) * d; cp[i] = sc[i] - (srad[i] + (real)0.5 * depth) * cn[i];
           }
+        }
+        if (L >= 1) {     // (ties: end A, as the oracle)
+          const V3 pe = B0.z < A0.z ? B0 : A0;
+          adepth[L - 1] = pe.z - (real)PIH_TABLE_Z - U_CAP_R[L];
+          apt[L - 1] = mk(pe.x, pe.y, pe.z - U_CAP_R[L] - (real)0.5 * adepth[L - 1]);
         }
         Rp = R; wp = wv[L]; vp = vv; opar = org;
       }
@@ -227,8 +241,8 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
     // object: m a = m g - damping ; I alpha = -w x I w - damping (world axes)
     const V3 ov = ld3(S + PIH_F_OVLIN), ow = ld3(S + PIH_F_OVANG);
     S3 Iow, Ioi;
-    { S3 d; d.xx = O_INERTIA[0]; d.yy = O_INERTIA[1]; d.zz = O_INERTIA[2]; d.xy = d.xz = d.yz = 0; Iow = rot_sym(Ro, d);
-      S3 e; e.xx = (real)1 / O_INERTIA[0]; e.yy = (real)1 / O_INERTIA[1]; e.zz = (real)1 / O_INERTIA[2]; e.xy = e.xz = e.yz = 0; Ioi = rot_sym(Ro, e); }
+    { S3 d; d.xx = O_INERTIA[ob][0]; d.yy = O_INERTIA[ob][1]; d.zz = O_INERTIA[ob][2]; d.xy = d.xz = d.yz = 0; Iow = rot_sym(Ro, d);
+      S3 e; e.xx = (real)1 / O_INERTIA[ob][0]; e.yy = (real)1 / O_INERTIA[ob][1]; e.zz = (real)1 / O_INERTIA[ob][2]; e.xy = e.xz = e.yz = 0; Ioi = rot_sym(Ro, e); }
     {
       const real sv = PIH_LIN_DAMP + PIH_LIN_DAMP * norm(ov), sw2 = PIH_ANG_DAMP + PIH_ANG_DAMP * norm(ow);
       const V3 Iw = mul(Iow, ow);
@@ -277,34 +291,41 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       lrl[j] = ((plo > 0 ? -plo / dt : -P.erp * plo / dt) - u[j]) * mdi[j];
       lrh[j] = ((phi > 0 ? -phi / dt : -P.erp * phi / dt) + u[j]) * mdi[j];
     }
-    // contact rows -> lane memory, compacted in slot order (slot i: sphere i vs arm; slot NS + i: sphere i vs table)
+    // contact rows -> lane memory, compacted in slot order (slot i: sphere i vs arm; slot NS + i: sphere i vs table; slot 2 NS + a: arm link
+    // 1 + a vs the table -- linkA = the arm link, no object part: n, rxn, wo stay 0 and the object's mass term is left out)
     //   record: 0-5 J arm | 6-11 W arm | 12-14 n | 15-17 (p - o_obj) x n | 18-20 I^-1 ((p - o_obj) x n) | 21 dinv | 22 rhs | 23 slot
     int nc = 0;
 #pragma unroll
     for (int k = 0; k < NC; k++) {
-      const int i = k < NS ? k : k - NS;
+      const int i = k < NS ? k : (k < 2 * NS ? k - NS : k - 2 * NS);
+      const bool armtab = k >= 2 * NS;
       bool valid; int la; V3 n, p; real depth;
       if (k < NS) { valid = clink[i] >= 0; la = clink[i]; n = cn[i]; p = cp[i]; depth = cdepth[i]; }
-      else { depth = sc[i].z - (real)PIH_TABLE_Z - O_SPH_R[i]; valid = depth < P.margin; landed = landed || depth < (real)0.002; la = -1; n = mk(0, 0, 1); p = mk(sc[i].x, sc[i].y, sc[i].z - O_SPH_R[i] - (real)0.5 * depth); }
+      else if (!armtab) { depth = sc[i].z - (real)PIH_TABLE_Z - srad[i]; valid = i < nsph && depth < P.margin; landed = landed || (i < nsph && depth < (real)0.002); la = -1; n = mk(0, 0, 1); p = mk(sc[i].x, sc[i].y, sc[i].z - srad[i] - (real)0.5 * depth); }
+      else { depth = adepth[i]; valid = depth < P.margin; la = 1 + i; n = mk(0, 0, 1); p = apt[i]; }
       if (valid) {
         real J[NJ], W[NJ];
+        const real sg = armtab ? (real)1 : (real)-1;       // the normal points from the other body to the object / from the table to the arm
 #pragma unroll
-        for (int L = 0; L < NJ; L++) J[L] = L <= la ? -dot(n, cross(a[L], p - o[L])) : (real)0;
-        if (la >= 0) arm_response(-1, la, p, -n, W);
+        for (int L = 0; L < NJ; L++) J[L] = L <= la ? sg * dot(n, cross(a[L], p - o[L])) : (real)0;
+        if (la >= 0) arm_response(-1, la, p, sg * n, W);
         else {
 #pragma unroll
           for (int L = 0; L < NJ; L++) W[L] = 0;
         }
-        const V3 rxn = cross(p - op, n), wo = mul(Ioi, rxn);
-        real jw = dot(n, n) * ((real)1 / (real)PIH_FLY_OBJ_MASS) + dot(rxn, wo), ju = dot(n, mk(u[6], u[7], u[8])) + dot(rxn, mk(u[9], u[10], u[11]));
+        const V3 no = armtab ? mk(0, 0, 0) : n;           // object part of the row
+        const V3 rxn = cross(p - op, no), wo = mul(Ioi, rxn);
+        real jw = dot(no, no) * omass_inv + dot(rxn, wo), ju = dot(no, mk(u[6], u[7], u[8])) + dot(rxn, mk(u[9], u[10], u[11]));
 #pragma unroll
         for (int L = 0; L < NJ; L++) { jw += J[L] * W[L]; ju += J[L] * u[L]; }
         const real di = (real)1 / jw, pen = depth + P.slop;
-        const real vb = pen > 0 ? -pen / dt : (real)0;      // banana.urdf:9 contact_erp 0: a penetrating contact is stopped, not pushed out [UNVERIFIED]
+        // object contacts: <contact_erp value="0.0"/> (banana.urdf:9, Amicelli_800_tex.urdf:9): a penetrating contact is stopped, not pushed out
+        // [UNVERIFIED]; arm vs table: Bullet's default contact ERP (ur5.urdf has no <contact> block)
+        const real vb = pen > 0 ? -pen / dt : (armtab ? -P.erp * pen / dt : (real)0);
         const int b = nc * CW;
 #pragma unroll
         for (int L = 0; L < NJ; L++) { mem.at(b + L) = J[L]; mem.at(b + 6 + L) = W[L]; }
-        mem.at(b + 12) = n.x; mem.at(b + 13) = n.y; mem.at(b + 14) = n.z; mem.at(b + 15) = rxn.x; mem.at(b + 16) = rxn.y; mem.at(b + 17) = rxn.z;
+        mem.at(b + 12) = no.x; mem.at(b + 13) = no.y; mem.at(b + 14) = no.z; mem.at(b + 15) = rxn.x; mem.at(b + 16) = rxn.y; mem.at(b + 17) = rxn.z;
         mem.at(b + 18) = wo.x; mem.at(b + 19) = wo.y; mem.at(b + 20) = wo.z; mem.at(b + 21) = di; mem.at(b + 22) = (vb - ju) * di; mem.at(b + 23) = 0;
         if (dbg && P.debug) { real* d = dbg + 16 + 10 * k; d[0] = 1; d[1] = (real)la; d[2] = p.x; d[3] = p.y; d[4] = p.z; d[5] = n.x; d[6] = n.y; d[7] = n.z; d[8] = depth; d[9] = (real)nc; }
         nc++;
@@ -353,7 +374,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         dl = sum - lam; mem.at(b + 23) = sum;
 #pragma unroll
         for (int L = 0; L < NJ; L++) du[L] += mem.at(b + 6 + L) * dl;
-        const real im = dl * ((real)1 / (real)PIH_FLY_OBJ_MASS);
+        const real im = dl * omass_inv;
         du[6] += n.x * im; du[7] += n.y * im; du[8] += n.z * im;
         du[9] += mem.at(b + 18) * dl; du[10] += mem.at(b + 19) * dl; du[11] += mem.at(b + 20) * dl;
         { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
@@ -364,7 +385,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
     for (int c = 0; c < nc; c++) cf += mem.at(c * CW + 23);
     if (dbg && P.debug) {
       dbg[12] = (real)nc; dbg[13] = (real)it;
-      for (int c = 0; c < nc; c++) dbg[116 + c] = mem.at(c * CW + 23);    // lambda_n of compacted contact c
+      for (int c = 0; c < nc; c++) dbg[200 + c] = mem.at(c * CW + 23);    // lambda_n of compacted contact c (contact records occupy words 16 .. 16 + 10 NC)
     }
     // ---- integrate
 #pragma unroll

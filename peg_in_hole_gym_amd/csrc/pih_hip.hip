@@ -219,11 +219,15 @@ __global__ void pih_gather_kernel(const float* __restrict__ state, float* __rest
 
 // ------------------------------------------------------------------------------------------------ 'random-fly' task kernels
 // One env per LANE (pih_fly.h).  state: float[PIH_FLY_STATE_WORDS][n] (structure-of-arrays: word w of the 64 envs of a wave is
-// one coalesced 256 B segment).  LDS: the per-lane contact rows, [word][lane].
+// one coalesced 256 B segment).  LDS: the per-lane contact rows, [word][lane] (92 KB per wave: one wave per CU; the kernel needs
+// 454 registers, i.e. one wave per SIMD, anyway).
+// (Measured on the MI355X, round 3, profiles/r03_fly_envs_per_wave.txt: packing FEWER envs into a wave -- 32 .. 4, i.e. 128 .. 1024
+//  waves for 4096 envs -- does not shorten the launch although the data-dependent PGS loop then waits for the slowest of fewer lanes,
+//  and from 512 waves on it lengthens it: the waves of a CU pair then contend for instruction fetch, SQ_WAIT_INST_ANY 2 % -> 52 %.)
 __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
                                                              float* __restrict__ obs, float* __restrict__ reward,
                                                              unsigned char* __restrict__ done, float* __restrict__ dbg, int n) {
-  __shared__ float lanemem[fly::LANE_WORDS * 64];
+  extern __shared__ float lanemem[];
   const int env = blockIdx.x * 64 + threadIdx.x;
   if (env >= n) return;
   float S[fly::SW];
@@ -332,6 +336,7 @@ static Params make_params(const pih_config* c) {
   P.ikiters = c->ik_iters; P.mode = c->mode; P.maxsteps = c->max_episode_steps; P.autoreset = c->auto_reset;
   P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball; P.noprio = (c->schedule & 4) != 0;
   P.checkstride = c->exit_check_stride < 1 ? 1 : c->exit_check_stride;
+  P.object = c->object_id;
   return P;
 }
 
@@ -365,6 +370,11 @@ int pih_task_dims(int task_id, int32_t out[3]) {
   return -2;
 }
 
+const char* pih_object_name(int task_id, int object_id) {
+  static const char* const names[PIH_FLY_NOBJ] = PIH_FLY_OBJ_NAMES;
+  return task_id == PIH_TASK_RANDOM_FLY && object_id >= 0 && object_id < PIH_FLY_NOBJ ? names[object_id] : nullptr;
+}
+
 int pih_destroy(pih_handle* h) {
   if (!h) return 0;
   DevGuard guard(h->device);
@@ -389,6 +399,8 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
     HIPCHK(h, hipMemcpy(*offd, offsets_host, (size_t)cfg->n_envs * 3 * sizeof(float), hipMemcpyHostToDevice));
   }
   if (h->fly) {
+    // (dynamic LDS beyond the default 64 KB limit: the per-lane contact rows of 64 envs are LANE_WORDS * 64 words = 92 KB of the CU's 160 KB)
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
     const int nb64 = (cfg->n_envs + 63) / 64;
     hipLaunchKernelGGL(pih_fly_init_offsets_kernel, dim3(nb64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
     hipLaunchKernelGGL(pih_fly_reset_kernel, dim3(nb64), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0, 0, cfg->n_envs);
@@ -415,6 +427,7 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
 int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** out) {
   if (!cfg || !out || cfg->n_envs <= 0) { g_err = "pih_create: bad arguments"; return -2; }
   if (cfg->task_id != PIH_TASK_PEG_IN_HOLE && cfg->task_id != PIH_TASK_RANDOM_FLY) { g_err = "pih_create: unknown task_id"; return -2; }
+  if (cfg->task_id == PIH_TASK_RANDOM_FLY && (cfg->object_id < 0 || cfg->object_id >= PIH_FLY_NOBJ)) { g_err = "pih_create: unknown object_id for the random-fly task"; return -2; }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) { g_err = "pih_create: no HIP device (this library has no CPU path)"; return -3; }
@@ -463,7 +476,8 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
   }
   if (h->fly) {   // one launch: controller + physics, one env per lane
     if (t) HIPCHK(h, hipEventRecord(t->b, s));
-    hipLaunchKernelGGL(pih_fly_step_kernel, dim3((h->cfg.n_envs + 63) / 64), dim3(64), 0, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs);
+    hipLaunchKernelGGL(pih_fly_step_kernel, dim3((h->cfg.n_envs + 63) / 64), dim3(64), (size_t)fly::LANE_WORDS * 64 * sizeof(float), s, h->P, h->state, actions, obs, reward, done,
+                       h->dbg, h->cfg.n_envs);
     if (t) HIPCHK(h, hipEventRecord(t->c, s));
     HIPCHK(h, hipGetLastError());
     return 0;

@@ -9,6 +9,17 @@ import numpy as np
 from .utils import Box
 
 
+def _objects_from_model_header():
+    """The object list of the 'random-fly' task = PIH_FLY_OBJ_NAMES of the GENERATED include/pih_model.h (tools/gen_model_header.py reads
+    every single-link free body under the reference's envs/assets/urdf); index = pih_config.object_id.  The library exports the same list
+    (pih_object_name), tests/test_abi_exports.py checks that the two agree."""
+    import os
+    import re
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "include", "pih_model.h")
+    m = re.search(r"#define PIH_FLY_OBJ_NAMES \{([^}]*)\}", open(hdr).read())
+    return tuple(re.findall(r'"([^"]+)"', m.group(1)))
+
+
 class MetaEnv(object):
     """Task plugin contract of the reference (envs/meta_env.py:8-42): class attrs action_space / observation_space;
     __init__(client, offset, args); apply_action, get_info -> (obs, reward, done, info), reset(hard_reset), render(mode).
@@ -100,7 +111,9 @@ class RandomFly(MetaEnv):
     """'random-fly' (README.md:38: task='random-fly', args=['Banana', 1/120.]): the UR5 of assets/urdf/ur5.urdf driven by
     ur_execute (envs/utils.py:70-82) next to one free-flying object spawned by random_pos_in_panda_space (envs/utils.py:97-107).
     The task class is not in the reference snapshot; rest pose, launch law, reward / done and observation are build-defined
-    (DESIGN.md section 9).  args[0] = object name (only 'Banana' is compiled in), args[1] = physics time step."""
+    (DESIGN.md section 9).  args[0] = object name -- one of OBJECTS, the single-link free bodies under envs/assets/urdf that
+    tools/gen_model_header.py turned into tables of include/pih_model.h (PIH_FLY_OBJ_NAMES: 'Banana', 'Amicelli'); its index is the
+    library's pih_config.object_id -- args[1] = physics time step."""
     action_space = Box(np.array([-1] * 6), np.array([1] * 6))       # ee target xyz + euler rpy (envs/utils.py:71-72)
     observation_space = Box(np.array([-1] * 6), np.array([1] * 6))  # ee xyz + object xyz (SURVEY.md 8d)
     task_id = 1
@@ -108,7 +121,7 @@ class RandomFly(MetaEnv):
     default_cfg = {"max_episode_steps": 480, "contact_margin": 0.02}   # margin = Bullet's contact breaking threshold (the object moves cm per step)
     urEndEffectorIndex = 7
     urNumDofs = 6
-    OBJECTS = ("Banana",)
+    OBJECTS = _objects_from_model_header()
 
     @classmethod
     def cfg_from_args(cls, args):
@@ -116,4 +129,7 @@ class RandomFly(MetaEnv):
             return {}
         if str(args[0]) not in cls.OBJECTS:
             raise ValueError("random-fly: object %r is not compiled into the library (available: %s)" % (args[0], ", ".join(cls.OBJECTS)))
-        return {"dt": float(args[1])} if len(args) > 1 else {}
+        kw = {"object_id": cls.OBJECTS.index(str(args[0]))}
+        if len(args) > 1:
+            kw["dt"] = float(args[1])
+        return kw

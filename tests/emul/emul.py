@@ -13,7 +13,7 @@ class PihConfig(C.Structure):
     """Mirror of pih_config (include/pih.h)."""
     _fields_ = [("n_envs", C.c_int32), ("env_index0", C.c_int32), ("mode", C.c_int32), ("solver_iters", C.c_int32),
                 ("ik_iters", C.c_int32), ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32),
-                ("enable_self_collision", C.c_int32), ("debug", C.c_int32), ("schedule", C.c_int32), ("enable_arm_collision", C.c_int32), ("task_id", C.c_int32), ("solver_path", C.c_int32), ("attach_ball", C.c_int32), ("exit_check_stride", C.c_int32), ("reserved_i", C.c_int32), ("seed", C.c_uint64),
+                ("enable_self_collision", C.c_int32), ("debug", C.c_int32), ("schedule", C.c_int32), ("enable_arm_collision", C.c_int32), ("task_id", C.c_int32), ("solver_path", C.c_int32), ("attach_ball", C.c_int32), ("exit_check_stride", C.c_int32), ("object_id", C.c_int32), ("seed", C.c_uint64),
                 ("dt", C.c_float), ("residual_threshold", C.c_float), ("erp", C.c_float), ("warmstart", C.c_float),
                 ("contact_margin", C.c_float), ("linear_slop", C.c_float), ("ik_damping", C.c_float), ("ik_residual", C.c_float),
                 ("dv", C.c_float), ("reserved_f", C.c_float * 3)]

@@ -58,6 +58,19 @@ def test_integration_md_stub_matches_the_abi():
     assert re.search(r"pih_reset\(h, None, int\(hard_reset\), C\.c_uint64\(0\), stream\)", code)
 
 
+def test_object_list_of_random_fly_comes_from_the_generated_header():
+    """RandomFly.OBJECTS (host), pih_object_name (library) and piho_fly_object_name (oracle) all list PIH_FLY_OBJ_NAMES of include/pih_model.h"""
+    from peg_in_hole_gym_amd import _lib
+    from peg_in_hole_gym_amd.envs.peg_in_hole import RandomFly
+    from oracle import oracle as O
+    assert list(RandomFly.OBJECTS) == _lib.object_names(_lib.TASK_RANDOM_FLY) == O.fly_object_names() == ["Banana", "Amicelli"]
+    assert _lib.object_names(_lib.TASK_PEG_IN_HOLE) == []
+    assert RandomFly.cfg_from_args(["Amicelli", 1 / 120.]) == {"object_id": 1, "dt": 1 / 120.}
+    import pytest
+    with pytest.raises(ValueError):
+        RandomFly.cfg_from_args(["Apple", 1 / 120.])
+
+
 def test_create_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -110,7 +110,38 @@ def test_ur5_dynamics_and_banana_tables_match_the_files(T):
         ax = int(np.argmax(hi - lo))
         assert A[k][ax] - R[k] >= lo[ax] - 1e-6 and B[k][ax] + R[k] <= hi[ax] + 1e-6
     b = T.banana_tables(REF)
-    assert _macro("PIH_FLY_OBJ_MASS") == b["mass"] == 1.0 and _macro("PIH_FLY_OBJ_MU") == b["friction"] == 0.0
-    assert int(_macro("PIH_FLY_OBJ_NSPH")) == len(b["hull_aabb"]) == 5
+    assert _macro("PIH_FLY_OBJ_MASS")[0] == b["mass"] == 1.0 and _macro("PIH_FLY_OBJ_MU")[0] == b["friction"] == 0.0
+    assert int(_macro("PIH_FLY_OBJ_NSPH")[0]) == len(b["hull_aabb"]) == 5
     ext = np.array(b["aabb"][1]) - np.array(b["aabb"][0]) + 0.002
-    np.testing.assert_allclose(_macro("PIH_FLY_OBJ_INERTIA"), T.box_inertia_diag(1.0, ext), rtol=1e-9)
+    np.testing.assert_allclose(_macro("PIH_FLY_OBJ_INERTIA")[0], T.box_inertia_diag(1.0, ext), rtol=1e-9)
+
+
+def test_every_free_body_and_the_hinged_board_of_the_reference_become_tables(T):
+    """SURVEY 8f-4 (asset -> task): the generator takes ANY single-link free body under envs/assets/urdf -- banana.urdf and
+    Amicelli_800_tex.urdf -- into the object table the random-fly kernel consumes (object_id = index, name = args[0] of README.md:38), and
+    reads charge_board.urdf (fixed base + one hinge with limits / damping, primitive cylinder) into PIH_DOOR_* tables."""
+    files = sorted(f for f in os.listdir(os.path.join(REF, "peg_in_hole_gym/envs/assets/urdf")) if f.endswith(".urdf"))
+    free = []
+    for f in files:
+        u = T.Urdf(os.path.join(REF, "peg_in_hole_gym/envs/assets/urdf", f))
+        if len(u.links) == 1 and not u.joints and f != "hole.urdf":      # (hole.urdf is the peg-in-hole scene's FIXED tube, envs/peg_in_hole.py:248-251)
+            free.append(f)
+    assert sorted(free) == sorted(T.FLY_OBJECT_FILES)                         # nothing left out
+    names = re.findall(r'"([^"]+)"', re.search(r"#define PIH_FLY_OBJ_NAMES \{([^}]*)\}", open(os.path.join(ROOT, "include", "pih_model.h")).read()).group(1))
+    assert names == [T.object_name(f) for f in T.FLY_OBJECT_FILES] == ["Banana", "Amicelli"]
+    am = T.free_body_tables(REF, "Amicelli_800_tex.urdf")
+    assert am["mass"] == 1.0 and am["friction"] == 0.0 and am["contact_erp"] == 0.0 and am["hull_nvert"] == [400]
+    assert _macro("PIH_FLY_OBJ_MASS")[1] == 1.0 and int(_macro("PIH_FLY_OBJ_NSPH")[1]) == len(am["sphere_r"]) == 2
+    lo, hi = np.array(am["aabb"][0]), np.array(am["aabb"][1])
+    np.testing.assert_allclose(_macro("PIH_FLY_OBJ_INERTIA")[1], T.box_inertia_diag(1.0, (hi - lo) + 0.002), rtol=1e-9)
+    C, R = np.array(_macro("PIH_FLY_OBJ_SPH_C")[1]), np.array(_macro("PIH_FLY_OBJ_SPH_R")[1])
+    ax = int(np.argmax(hi - lo))
+    for k in range(2):                                                         # the spheres stay inside the mesh's AABB along its long axis and touch its ends
+        assert lo[ax] - 1e-6 <= C[k][ax] - R[k] and C[k][ax] + R[k] <= hi[ax] + 1e-6
+    assert abs((C[0][ax] - R[0]) - lo[ax]) < 1e-6 and abs((C[1][ax] + R[1]) - hi[ax]) < 1e-6 and (R[2:] == 0).all()
+    np.testing.assert_allclose(_macro("PIH_FLY_OBJ_RGB")[1], [0.431, 0.185, 0.327])
+    d = T.hinged_body_tables(REF)
+    assert _macro("PIH_DOOR_LO") == d["lower"] == -2.09439510239 and _macro("PIH_DOOR_HI") == 0.0 and _macro("PIH_DOOR_DAMPING") == 1.0
+    np.testing.assert_allclose(_macro("PIH_DOOR_HINGE_AXIS"), [0, 0, 1]); np.testing.assert_allclose(_macro("PIH_DOOR_BASE_T"), [0.04, 0, 0])
+    np.testing.assert_allclose(np.abs(_macro("PIH_DOOR_CYL_AXIS")), [0, 1, 0], atol=1e-9)    # <origin rpy="1.5708 0 0">: the disc's axis is the door's y
+    assert _macro("PIH_DOOR_CYL_R") == 0.04 and _macro("PIH_DOOR_CYL_HALFLEN") == 0.005

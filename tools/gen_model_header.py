@@ -12,8 +12,11 @@ Sources (reference paths relative to /root/reference/peg_in_hole_gym/):
             (envs/peg_in_hole.py:235, envs/utils.py:24-28).
   * ur5   : envs/assets/urdf/ur5.urdf:32-218,534-539 (exact).
 
-  * banana: envs/assets/urdf/banana.urdf:1-32 + obj/banana_collision.obj (5 convex hulls) -- the free-flying object of
-            the 'random-fly' task (README.md:38).
+  * free bodies: envs/assets/urdf/banana.urdf:1-32 + obj/banana_collision.obj (5 convex hulls) and
+            envs/assets/urdf/Amicelli_800_tex.urdf:1-33 + obj/Amicelli_800_tex.obj (one closed mesh) -- the free-flying objects
+            of the 'random-fly' task, selected by args[0] (README.md:38: args=['Banana', 1/120.]).
+  * charge_board: envs/assets/urdf/charge_board.urdf:1-40 (fixed base + one hinged door, primitive cylinder): tables only (no task
+            of the snapshot uses it).
 
 Everything that exists in the reference tree is READ from it (tools/urdf_tables.py: URDF via xml.etree, fixed-joint merge,
 globalScaling, OBJ / binary-STL collision meshes for the AABB box-inertia rule); only the Panda and the table, whose assets
@@ -37,7 +40,8 @@ REF = sys.argv[sys.argv.index("--ref") + 1] if "--ref" in sys.argv else "/root/r
 PIPE = UT.pipe_tables(REF)
 HOLE = UT.hole_tables(REF)
 UR5 = UT.ur5_tables(REF)
-BANANA = UT.banana_tables(REF)
+OBJECTS = [UT.free_body_tables(REF, f) for f in UT.FLY_OBJECT_FILES]
+DOOR = UT.hinged_body_tables(REF)
 MARGIN = 0.001          # pybullet's default collision margin for URDF meshes [UNVERIFIED, SURVEY.md App. C]
 DEFAULT_MU = 0.5        # pybullet's default lateral friction for links without a <contact> block
 
@@ -302,19 +306,43 @@ print("#define PIH_UR5_CAP_B {" + ", ".join(arr(np.round(c[1], 9)) for c in caps
 print("#define PIH_UR5_CAP_R " + arr(round(c[2], 9) for c in caps))
 print("#define PIH_UR5_REST {0.0, %s, %s, %s, %s, 0.0}   /* BUILD-DEFINED rest pose (the reference passes ur_orn from a task that is not in the snapshot) */" % (
     fmt(-math.pi / 2), fmt(math.pi / 2), fmt(-math.pi / 2), fmt(-math.pi / 2)))
-# ----------------------------------------------------------------------------- banana (envs/assets/urdf/banana.urdf + obj/banana_collision.obj)
-blo, bhi = np.array(BANANA["aabb"][0]), np.array(BANANA["aabb"][1])
-bI = box_inertia(BANANA["mass"], *((bhi - blo) + 2 * MARGIN))
-print("/* free-flying object of the random-fly task: banana.urdf:1-32 (1 kg, lateral_friction 0, contact_erp 0), inertia = AABB box of")
-print(" * banana_collision.obj; collision = one sphere per convex hull of that file (centre = hull AABB centre, radius = mean half extent:")
-print(" * BUILD-DEFINED stand-in for the 5 hulls with %s vertices) */" % "/".join(str(n) for n in BANANA["hull_nvert"]))
-print("#define PIH_FLY_OBJ_MASS %s" % fmt(BANANA["mass"]))
-print("#define PIH_FLY_OBJ_INERTIA " + arr(np.diag(bI)) + "   /* xx yy zz about the inertial origin (banana.urdf:12), body axes */")
-print("#define PIH_FLY_OBJ_MU %s" % fmt(BANANA["friction"]))
-print("#define PIH_FLY_OBJ_NSPH %d" % len(BANANA["hull_aabb"]))
-hc = [0.5 * (np.array(a) + np.array(b)) for a, b in BANANA["hull_aabb"]]
-hr = [float(np.mean(0.5 * (np.array(b) - np.array(a)))) for a, b in BANANA["hull_aabb"]]
-print("#define PIH_FLY_OBJ_SPH_C {" + ", ".join(arr(np.round(c, 9)) for c in hc) + "}")
-print("#define PIH_FLY_OBJ_SPH_R " + arr(round(r, 9) for r in hr))
-print("#define PIH_FLY_OBJ_RGB " + arr(BANANA["rgba"][:3]) + "   /* <material> colour, banana.urdf:21-23 */")
+# ----------------------------------------------------------------------------- free-flying objects of the random-fly task
+MAXSPH = max(len(o["sphere_r"]) for o in OBJECTS)
+print("/* free-flying objects of the random-fly task, object_id = index (pih_config.object_id; args[0] of README.md:38 names one): every")
+print(" * single-link free body under envs/assets/urdf -- " + ", ".join("%s (%s, %s: %s hull%s with %s vertices)" % (
+    UT.object_name(o["urdf"]), o["urdf"], o["mesh"], len(o["hull_nvert"]), "" if len(o["hull_nvert"]) == 1 else "s", "/".join(str(n) for n in o["hull_nvert"])) for o in OBJECTS) + ".")
+print(" * mass / lateral_friction / contact_erp from the URDF; inertia = AABB box of the collision mesh (pybullet's rule without")
+print(" * URDF_USE_INERTIA_FROM_FILE); collision = spheres by tools/urdf_tables.py cover_with_spheres (BUILD-DEFINED stand-in for the hulls:")
+print(" * one sphere per hull of a multi-hull file, a row of spheres along the longest axis of a single-hull file), padded to MAXSPH */")
+print("#define PIH_FLY_NOBJ %d" % len(OBJECTS))
+print("#define PIH_FLY_OBJ_NAMES {" + ", ".join('"%s"' % UT.object_name(o["urdf"]) for o in OBJECTS) + "}")
+print("#define PIH_FLY_OBJ_MAXSPH %d" % MAXSPH)
+print("#define PIH_FLY_OBJ_MASS " + arr(o["mass"] for o in OBJECTS))
+inert = []
+for o in OBJECTS:
+    lo, hi = np.array(o["aabb"][0]), np.array(o["aabb"][1])
+    inert.append(np.diag(box_inertia(o["mass"], *((hi - lo) + 2 * MARGIN))))
+print("#define PIH_FLY_OBJ_INERTIA {" + ", ".join(arr(i) for i in inert) + "}   /* xx yy zz about the inertial origin, body axes */")
+print("#define PIH_FLY_OBJ_MU " + arr(o["friction"] for o in OBJECTS))
+print("#define PIH_FLY_OBJ_CONTACT_ERP " + arr(o["contact_erp"] for o in OBJECTS))
+print("#define PIH_FLY_OBJ_NSPH " + iarr(len(o["sphere_r"]) for o in OBJECTS))
+print("#define PIH_FLY_OBJ_SPH_C {" + ", ".join("{" + ", ".join(arr(np.round(c, 9)) for c in (o["sphere_c"] + [[0.0, 0.0, 0.0]] * MAXSPH)[:MAXSPH]) + "}" for o in OBJECTS) + "}")
+print("#define PIH_FLY_OBJ_SPH_R {" + ", ".join(arr(round(r, 9) for r in (o["sphere_r"] + [0.0] * MAXSPH)[:MAXSPH]) for o in OBJECTS) + "}")
+print("#define PIH_FLY_OBJ_RGB {" + ", ".join(arr(o["rgba"][:3]) for o in OBJECTS) + "}   /* <material> colour */")
+# ----------------------------------------------------------------------------- charge_board.urdf (tables only)
+print("/* envs/assets/urdf/charge_board.urdf:1-40: fixed base + ONE hinged door (no task of the snapshot loads it; emitted so that the reader")
+print(" * is exercised on a revolute joint with limits / damping and a primitive <cylinder>): hinge in the base frame, door mass, inertia by")
+print(" * pybullet's AABB rule next to the file's values, the cylinder in the door frame */")
+print("#define PIH_DOOR_BASE_T " + arr(DOOR["base_xyz"]))
+print("#define PIH_DOOR_HINGE_T " + arr(DOOR["hinge_xyz"]))
+print("#define PIH_DOOR_HINGE_AXIS " + arr(DOOR["hinge_axis"]))
+print("#define PIH_DOOR_LO %s" % fmt(DOOR["lower"]))
+print("#define PIH_DOOR_HI %s" % fmt(DOOR["upper"]))
+print("#define PIH_DOOR_DAMPING %s" % fmt(DOOR["damping"]))
+print("#define PIH_DOOR_MASS %s" % fmt(DOOR["mass"]))
+print("#define PIH_DOOR_INERTIA " + arr(DOOR["inertia_rule"]) + "   /* AABB rule; the file says " + arr(DOOR["inertia_file"]) + " */")
+print("#define PIH_DOOR_CYL_C " + arr(DOOR["cyl_xyz"]))
+print("#define PIH_DOOR_CYL_AXIS " + arr(DOOR["cyl_axis"]))
+print("#define PIH_DOOR_CYL_R %s" % fmt(DOOR["cyl_radius"]))
+print("#define PIH_DOOR_CYL_HALFLEN %s" % fmt(0.5 * DOOR["cyl_length"]))
 print("#endif")

@@ -172,19 +172,103 @@ def ur5_tables(ref_root):
             "ee_mass": u.links[ee]["mass"], "ee_com": u.links[ee]["com"], "ee_aabb": [a.tolist() for a in u.mesh_aabb(ee)]}
 
 
+def _urdf_extras(path):
+    """<contact> children and <collision><geometry><cylinder> of every link (fields the small Urdf class does not keep)"""
+    root = ET.parse(path).getroot()
+    out = {}
+    for l in root.findall("link"):
+        d = {"contact_erp": None, "cylinder": None, "inertia_diag": None}
+        c = l.find("contact")
+        if c is not None and c.find("contact_erp") is not None:
+            d["contact_erp"] = float(c.find("contact_erp").get("value"))
+        ine = l.find("inertial")
+        if ine is not None and ine.find("inertia") is not None:
+            i = ine.find("inertia"); d["inertia_diag"] = [float(i.get(k)) for k in ("ixx", "iyy", "izz")]
+        col = l.find("collision")
+        if col is not None and col.find("geometry") is not None and col.find("geometry").find("cylinder") is not None:
+            cy = col.find("geometry").find("cylinder"); o = col.find("origin")
+            d["cylinder"] = {"radius": float(cy.get("radius")), "length": float(cy.get("length")),
+                             "xyz": _floats(o.get("xyz") if o is not None else None), "rpy": _floats(o.get("rpy") if o is not None else None)}
+        out[l.get("name")] = d
+    return out
+
+
+def cover_with_spheres(hulls):
+    """Sphere stand-in for the convex collision hulls of a free body (BUILD-DEFINED rule, the same for every object):
+      * a file that comes as SEVERAL hulls (banana_collision.obj: one `o` group per hull of a convex decomposition) gets one sphere per
+        hull: centre = the hull's AABB centre, radius = the mean of its three half extents;
+      * a file with ONE hull (Amicelli_800_tex.obj: a single closed mesh, which pybullet wraps in its convex hull) gets a row of spheres
+        along the longest AABB axis: radius r = mean of the two other half extents, count = ceil(longest half extent / r), centres evenly
+        spaced so that the end spheres touch the ends of the AABB."""
+    if len(hulls) > 1:
+        return [(0.5 * (h.min(0) + h.max(0)), float(np.mean(0.5 * (h.max(0) - h.min(0))))) for h in hulls]
+    h = hulls[0]
+    c = 0.5 * (h.min(0) + h.max(0)); he = 0.5 * (h.max(0) - h.min(0))
+    ax = int(np.argmax(he))
+    r = float(np.mean([he[i] for i in range(3) if i != ax]))
+    n = max(1, int(math.ceil(he[ax] / r)))
+    span = max(he[ax] - r, 0.0)
+    out = []
+    for k in range(n):
+        t = 0.0 if n == 1 else -span + 2 * span * k / (n - 1)
+        e = np.zeros(3); e[ax] = t
+        out.append((c + e, r))
+    return out
+
+
+def free_body_tables(ref_root, urdf_file):
+    """A single-link free body of the reference (envs/assets/urdf/banana.urdf, Amicelli_800_tex.urdf): mass, inertial origin, lateral
+    friction, contact_erp, colour and its collision mesh (one convex hull per `o` group of the OBJ, or the whole file as one hull)."""
+    path = os.path.join(ref_root, "peg_in_hole_gym/envs/assets/urdf", urdf_file)
+    u = Urdf(path)
+    assert len(u.links) == 1 and not u.joints, "%s is not a single free body" % urdf_file
+    name, l = next(iter(u.links.items()))
+    ex = _urdf_extras(path)[name]
+    mesh = os.path.normpath(os.path.join(os.path.dirname(u.path), l["collision"]["mesh"]))
+    hulls = obj_hulls(mesh) or [obj_vertices(mesh)]
+    allv = np.concatenate(hulls)
+    sph = cover_with_spheres(hulls)
+    return {"urdf": urdf_file, "link": name, "mass": l["mass"], "com": l["com"], "friction": l["friction"], "contact_erp": ex["contact_erp"], "rgba": l["rgba"],
+            "mesh": os.path.basename(mesh), "aabb": [allv.min(0).tolist(), allv.max(0).tolist()],
+            "hull_aabb": [[h.min(0).tolist(), h.max(0).tolist()] for h in hulls], "hull_nvert": [len(h) for h in hulls],
+            "sphere_c": [c.tolist() for c, _ in sph], "sphere_r": [r for _, r in sph]}
+
+
+def object_name(urdf_file):
+    """args[0] of the reference's usage line (README.md:38 `args=['Banana', 1/120.]`) for an asset file: the file stem up to the first
+    underscore, capitalised (banana.urdf -> 'Banana', Amicelli_800_tex.urdf -> 'Amicelli')"""
+    stem = os.path.splitext(urdf_file)[0].split("_")[0]
+    return stem[0].upper() + stem[1:]
+
+
+FLY_OBJECT_FILES = ("banana.urdf", "Amicelli_800_tex.urdf")      # every single-link free body under envs/assets/urdf, in this order = object_id
+
+
 def banana_tables(ref_root):
     """envs/assets/urdf/banana.urdf:1-32 + obj/banana_collision.obj (one convex hull per `o` group)."""
-    u = Urdf(os.path.join(ref_root, "peg_in_hole_gym/envs/assets/urdf/banana.urdf"))
-    l = u.links["banana"]
-    hulls = obj_hulls(os.path.normpath(os.path.join(os.path.dirname(u.path), l["collision"]["mesh"])))
-    allv = np.concatenate(hulls)
-    return {"mass": l["mass"], "com": l["com"], "friction": l["friction"], "rgba": l["rgba"],
-            "aabb": [allv.min(0).tolist(), allv.max(0).tolist()],
-            "hull_aabb": [[h.min(0).tolist(), h.max(0).tolist()] for h in hulls], "hull_nvert": [len(h) for h in hulls]}
+    return free_body_tables(ref_root, "banana.urdf")
+
+
+def hinged_body_tables(ref_root, urdf_file="charge_board.urdf"):
+    """A fixed base with ONE revolute link (envs/assets/urdf/charge_board.urdf: world -> door_base fixed, door_base -> door hinge with a
+    primitive cylinder as collision shape): hinge origin / axis / limits / damping, door mass, the file's inertia and the inertia by
+    pybullet's rule (box of the collision AABB), and the cylinder in the door frame."""
+    path = os.path.join(ref_root, "peg_in_hole_gym/envs/assets/urdf", urdf_file)
+    u = Urdf(path); ex = _urdf_extras(path)
+    rev = [j for j in u.joints if j["type"] == "revolute"]; fixed = [j for j in u.joints if j["type"] == "fixed"]
+    assert len(rev) == 1 and len(fixed) == 1, "%s is not a fixed base with one hinge" % urdf_file
+    j = rev[0]; door = j["child"]; cy = ex[door]["cylinder"]
+    R = rpy_matrix(*cy["rpy"]); axis = R @ np.array([0.0, 0.0, 1.0])          # a URDF cylinder is along its local z
+    half = np.abs(axis) * 0.5 * cy["length"] + (1 - np.abs(axis)) * cy["radius"]   # AABB half extents of the (axis-aligned) cylinder
+    return {"urdf": urdf_file, "base_xyz": fixed[0]["xyz"], "hinge_xyz": j["xyz"], "hinge_axis": j["axis"], "lower": float(j["lower"]), "upper": float(j["upper"]),
+            "damping": j["damping"], "mass": u.links[door]["mass"], "inertia_file": ex[door]["inertia_diag"],
+            "inertia_rule": box_inertia_diag(u.links[door]["mass"], 2 * half + 0.002), "cyl_radius": cy["radius"], "cyl_length": cy["length"],
+            "cyl_xyz": cy["xyz"], "cyl_axis": axis.round(12).tolist()}
 
 
 if __name__ == "__main__":
     import json
     import sys
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
-    print(json.dumps({"pipe": pipe_tables(ref), "hole": hole_tables(ref), "ur5": ur5_tables(ref), "banana": banana_tables(ref)}, indent=1)[:6000])
+    print(json.dumps({"pipe": pipe_tables(ref), "hole": hole_tables(ref), "ur5": ur5_tables(ref), "objects": [free_body_tables(ref, f) for f in FLY_OBJECT_FILES],
+                      "charge_board": hinged_body_tables(ref)}, indent=1)[:9000])
