@@ -206,3 +206,47 @@ def test_hand_spheres_stop_the_pipe(oracle_mod):
     print("pipe dropped on the wrist sphere: base z after 40 steps %.3f with arm-vs-pipe spheres (%d steps in contact), %.3f without" % (zs[3][0], zs[3][1], zs[1][0]))
     assert zs[3][1] > 20 and zs[3][2] > -2e-3                      # carried by the sphere without sinking into it (it see-saws and will slide off eventually)
     assert zs[1][1] == 0 and zs[1][0] < zs[3][0] - 0.03            # falls freely without the spheres
+
+
+def _straight_pipe_under_the_arm(o, yaws):
+    """every env: a STRAIGHT pipe at rest on the table under the arm's workspace, base at (0, -0.5), heading `yaw`; the root link is the one to grasp"""
+    s = o.get_state()
+    for e, yaw in enumerate(yaws):
+        s[e, 31:54] = 0; s[e, 54:77] = 0; s[e, 25:31] = 0
+        s[e, 18:21] = [0.0, -0.5, -0.04 + 1e-4]
+        s[e, 21:25] = [0, 0, np.sin(yaw / 2), np.cos(yaw / 2)]
+        s[e, 89] = 0; s[e, 90] = 0.0          # grasp link 0 (pipe_link1), random_vector = 0
+    o.set_state(s)
+
+
+def test_known_answer_episode_inserts_the_peg(oracle_mod):
+    """KNOWN ANSWER for the scripted episode (envs/peg_in_hole.py:53-116): a straight pipe lying under the arm with its axis along
+    world y (heading 0 and 22.5 degrees -- the headings for which the reference's commanded wrist rotations stay inside the Panda's
+    joint limits and its childFrameOrientation quirk, envs/peg_in_hole.py:101, is small) is approached, grasped, carried through
+    states 4-6 and released with the grasped link inside the hole: reward 1 at the end of the episode, the link within 5 cm of the
+    hole from the end of state 6 on, and no contact-force spike (the 20 kN finger squeeze of :154 on the welded link stays far below
+    the 1e5 N events of DESIGN.md 5.3).  tools/scripted_causes.py attributes the episodes that do NOT end like this."""
+    N = 2
+    o = oracle_mod.Oracle(N, mode=1, dv=0.05, seed=3)
+    _straight_pipe_under_the_arm(o, [0.0, np.pi / 8])
+    hole = np.array([0.5, -0.2, 0.2])
+    a = np.zeros((N, 4)); fmax = np.zeros(N); dist = {}
+    for t in range(2226):
+        obs, rew, done = o.step(a)
+        fmax = np.maximum(fmax, np.abs(o.contact_force()))
+        if t + 1 in (2105, 2165, 2226):
+            dist[t + 1] = np.linalg.norm(o.tip_pose()[:, :3] - hole, axis=1)
+    assert done.all() and (rew == 1).all(), (rew, dist)
+    for k, d in dist.items():
+        assert (d < 0.05).all(), (k, d)
+    assert fmax.max() < 5e4, fmax
+
+
+def test_cause_table_tool_runs():
+    """tools/scripted_causes.py (the per-episode cause histogram quoted in DESIGN.md) on a small batch: every episode is attributed"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "scripted_causes.py"), "16"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    rows = {l.split("%")[0].rsplit(None, 1)[0].strip(): float(l.split("%")[0].rsplit(None, 1)[1]) for l in out.stdout.splitlines() if l.startswith("  ")}
+    assert set(rows) == {"reach", "carry", "release", "retreat", "ok", "ok (returned)"} and abs(sum(rows.values()) - 100.0) < 0.5
