@@ -223,7 +223,7 @@ template <class C, class W> PIH_HD void ik_chain(W& w, real (*ik_T)[12], const P
       real qq = q[0];
 #pragma unroll
       for (int k = 1; k < N; k++) qq = (L == k) ? q[k] : qq;
-      M3 R = mul(ldm(C::rfix(L)), axis_angle(ld3(C::axis(L)), qq));
+      M3 R = mul(ldm(C::rfix(L)), axis_angle_joint(ld3(C::axis(L)), qq));
       stm(ik_T[L], R); st3(ik_T[L] + 9, ld3(C::tfix(L)));
     });
     V3 a[N], o[N];

@@ -416,7 +416,7 @@ def test_arm_table_contact_on_gpu(torch_mod, oracle_mod):
         led.after(o, a, np.abs(so[:, POS] - sg[:, POS]).max(1))
         lowest = min(lowest, oracle_mod.fk_arm(so[0, 0:9], 9)[0][2])
     assert seen > 50 and lowest > -0.05 - 0.004
-    led.finish("arm-table contacts", exempt_share=0.05, check_force=False)
+    led.finish("arm-table contacts", exempt_share=0.05, p99=5e-5, check_force=False)
 
 
 def test_joint_limit_rows_on_gpu(torch_mod, oracle_mod):
