@@ -28,7 +28,9 @@ constexpr int NA = 5;                                       // arm-vs-table slot
 constexpr int NC = 2 * NS + NA;    // contact slots: sphere s vs its deepest arm capsule, sphere s vs the table, arm link 1 + a vs the table
 constexpr int SW = PIH_FLY_STATE_WORDS;
 constexpr int CW = 24;             // words of one contact row record in lane memory
-constexpr int LANE_WORDS = NC * CW;
+constexpr int KW = 8;              // words of one contact CANDIDATE of a slot (staged for the rolled row-build loop)
+constexpr int CAND0 = NC * CW;     // candidates follow the (compacted) row records
+constexpr int LANE_WORDS = NC * CW + NC * KW;
 
 PIH_CONST real U_MASS[NJ] = PIH_UR5_MASS;
 PIH_CONST real U_COM[NJ][3] = PIH_UR5_COM;
@@ -177,25 +179,33 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         const real sv = PIH_LIN_DAMP + PIH_LIN_DAMP * norm(vc), sw2 = PIH_ANG_DAMP + PIH_ANG_DAMP * norm(wv[L]);
         const V3 f = m * cross(wv[L], wrc) - mk(0, 0, m * (real)PIH_GRAVITY_Z) + (m * sv) * vc;
         pl[L] = f; pa[L] = cross(wv[L], Iw) + sw2 * Iw + cross(rc, f);
-        // collision: every object sphere against this link's capsule; keep the deepest per sphere (ties: lowest link)
+        // collision capsule of the link (world): staged in lane memory for the rolled sphere-vs-capsule loop below
         const V3 A0 = org + mul(R, ld3(U_CAP_A[L])), B0 = org + mul(R, ld3(U_CAP_B[L]));
-        const V3 ab = B0 - A0; const real l2 = dot(ab, ab);
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-          const V3 ac = sc[i] - A0;
-          const real t = l2 > (real)1e-18 ? clampr(dot(ac, ab) / l2, 0, 1) : (real)0;
-          const V3 d = sc[i] - (A0 + t * ab);
-          const real dist = norm(d), depth = dist - srad[i] - U_CAP_R[L];
-          if (i < nsph && depth < P.margin && depth < cdepth[i] && dist > (real)1e-9) {
-            cdepth[i] = depth; clink[i] = L; cn[i] = ((real)1 / dist) * d; cp[i] = sc[i] - (srad[i] + (real)0.5 * depth) * cn[i];
-          }
-        }
+        mem.at(6 * L) = A0.x; mem.at(6 * L + 1) = A0.y; mem.at(6 * L + 2) = A0.z; mem.at(6 * L + 3) = B0.x; mem.at(6 * L + 4) = B0.y; mem.at(6 * L + 5) = B0.z;
         if (L >= 1) {     // (ties: end A, as the oracle)
           const V3 pe = B0.z < A0.z ? B0 : A0;
           adepth[L - 1] = pe.z - (real)PIH_TABLE_Z - U_CAP_R[L];
           apt[L - 1] = mk(pe.x, pe.y, pe.z - U_CAP_R[L] - (real)0.5 * adepth[L - 1]);
         }
         Rp = R; wp = wv[L]; vp = vv; opar = org;
+      }
+    }
+    // collision: every object sphere against every link's capsule; keep the deepest per sphere (ties: lowest link).  ONE rolled loop over
+    // the links (capsule end points from lane memory, words 0 .. 35: the row records that will live there are written later) instead of
+    // six inlined copies of the five sphere tests: code size
+#pragma nounroll
+    for (int L = 0; L < NJ; L++) {
+      const V3 A0 = mk(mem.at(6 * L), mem.at(6 * L + 1), mem.at(6 * L + 2)), B0 = mk(mem.at(6 * L + 3), mem.at(6 * L + 4), mem.at(6 * L + 5));
+      const V3 ab = B0 - A0; const real l2 = dot(ab, ab), capr = U_CAP_R[L];
+#pragma unroll
+      for (int i = 0; i < NS; i++) {
+        const V3 ac = sc[i] - A0;
+        const real t = l2 > (real)1e-18 ? clampr(dot(ac, ab) / l2, 0, 1) : (real)0;
+        const V3 d = sc[i] - (A0 + t * ab);
+        const real dist = norm(d), depth = dist - srad[i] - capr;
+        if (i < nsph && depth < P.margin && depth < cdepth[i] && dist > (real)1e-9) {
+          cdepth[i] = depth; clink[i] = L; cn[i] = ((real)1 / dist) * d; cp[i] = sc[i] - (srad[i] + (real)0.5 * depth) * cn[i];
+        }
       }
     }
     // ---- ABA inward sweep: U = I^A S, D, u; hand (I^a, p^a) up to the parent's origin
@@ -291,19 +301,35 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       lrl[j] = ((plo > 0 ? -plo / dt : -P.erp * plo / dt) - u[j]) * mdi[j];
       lrh[j] = ((phi > 0 ? -phi / dt : -P.erp * phi / dt) + u[j]) * mdi[j];
     }
-    // contact rows -> lane memory, compacted in slot order (slot i: sphere i vs arm; slot NS + i: sphere i vs table; slot 2 NS + a: arm link
-    // 1 + a vs the table -- linkA = the arm link, no object part: n, rxn, wo stay 0 and the object's mass term is left out)
-    //   record: 0-5 J arm | 6-11 W arm | 12-14 n | 15-17 (p - o_obj) x n | 18-20 I^-1 ((p - o_obj) x n) | 21 dinv | 22 rhs | 23 slot
-    int nc = 0;
+    // contact candidates of all NC slots -> lane memory (slot i: sphere i vs arm; slot NS + i: sphere i vs table; slot 2 NS + a: arm link
+    // 1 + a vs the table): word 0 = link + 2 (0 = slot empty, 1 = no arm link), 1-3 n, 4-6 p, 7 depth.  Staged so that the row build below is
+    // ONE rolled loop: as 15 inlined copies (each with its own impulse-response sweep) it was a third of the kernel's 75 KB of code, which
+    // 8 waves per instruction cache do not fit.
 #pragma unroll
     for (int k = 0; k < NC; k++) {
       const int i = k < NS ? k : (k < 2 * NS ? k - NS : k - 2 * NS);
-      const bool armtab = k >= 2 * NS;
       bool valid; int la; V3 n, p; real depth;
       if (k < NS) { valid = clink[i] >= 0; la = clink[i]; n = cn[i]; p = cp[i]; depth = cdepth[i]; }
-      else if (!armtab) { depth = sc[i].z - (real)PIH_TABLE_Z - srad[i]; valid = i < nsph && depth < P.margin; landed = landed || (i < nsph && depth < (real)0.002); la = -1; n = mk(0, 0, 1); p = mk(sc[i].x, sc[i].y, sc[i].z - srad[i] - (real)0.5 * depth); }
+      else if (k < 2 * NS) { depth = sc[i].z - (real)PIH_TABLE_Z - srad[i]; valid = i < nsph && depth < P.margin; landed = landed || (i < nsph && depth < (real)0.002); la = -1; n = mk(0, 0, 1); p = mk(sc[i].x, sc[i].y, sc[i].z - srad[i] - (real)0.5 * depth); }
       else { depth = adepth[i]; valid = depth < P.margin; la = 1 + i; n = mk(0, 0, 1); p = apt[i]; }
+      const int b = CAND0 + k * KW;
+      mem.at(b) = valid ? (real)(la + 2) : (real)0;
+      mem.at(b + 1) = n.x; mem.at(b + 2) = n.y; mem.at(b + 3) = n.z; mem.at(b + 4) = p.x; mem.at(b + 5) = p.y; mem.at(b + 6) = p.z; mem.at(b + 7) = depth;
+    }
+    // contact rows -> lane memory, compacted in slot order (arm-vs-table slots: linkA = the arm link, no object part: n, rxn, wo stay 0 and
+    // the object's mass term is left out)
+    //   record: 0-5 J arm | 6-11 W arm | 12-14 n | 15-17 (p - o_obj) x n | 18-20 I^-1 ((p - o_obj) x n) | 21 dinv | 22 rhs | 23 lambda
+    int nc = 0;
+#pragma nounroll
+    for (int k = 0; k < NC; k++) {
+      const bool armtab = k >= 2 * NS;
+      const int kb = CAND0 + k * KW;
+      const real tag = mem.at(kb);
+      const bool valid = tag != (real)0;
       if (valid) {
+        const int la = (int)tag - 2;
+        const V3 n = mk(mem.at(kb + 1), mem.at(kb + 2), mem.at(kb + 3)), p = mk(mem.at(kb + 4), mem.at(kb + 5), mem.at(kb + 6));
+        const real depth = mem.at(kb + 7);
         real J[NJ], W[NJ];
         const real sg = armtab ? (real)1 : (real)-1;       // the normal points from the other body to the object / from the table to the arm
 #pragma unroll
