@@ -406,7 +406,7 @@ def test_arm_table_contact_on_gpu(torch_mod, oracle_mod):
     o = oracle_mod.Oracle(N, **kw); g = _gpu(N, **kw); led = P.ConditionedParity(oracle_mod, with_cache=False, slots=128, **kw)
     p0, _ = oracle_mod.fk_arm(REST, 9)
     a = np.tile([p0[0] + 0.25, p0[1] - 0.25, -1.0, 0.04], (N, 1))
-    seen = 0; lowest = 1.0
+    seen = 0; lowest = 1.0; variants = np.zeros(6, int)
     for t in range(420):
         _to_gpu_state(torch, g, o.get_state()); led.before(o)
         o.step(a); g.step(torch.tensor(a, dtype=torch.float32))
@@ -415,8 +415,37 @@ def test_arm_table_contact_on_gpu(torch_mod, oracle_mod):
         seen += any(int(k) >= 3000 for k in o.debug_contacts(0)[:, 10])
         led.after(o, a, np.abs(so[:, POS] - sg[:, POS]).max(1))
         lowest = min(lowest, oracle_mod.fk_arm(so[0, 0:9], 9)[0][2])
+        variants += np.bincount(sg[:, 114].astype(int), minlength=6)
+    print("arm-table: solver variants (state word 114) histogram:", variants.tolist())
     assert seen > 50 and lowest > -0.05 - 0.004
     led.finish("arm-table contacts", exempt_share=0.05, p99=5e-5, check_force=False)
+
+
+def test_clamped_arm_motor_reruns_with_limit_rows(torch_mod, oracle_mod):
+    """The solve that leaves out the limit rows of arm joints 0..6 (pih_wave.h: skip7) is only valid while no arm motor row clamps; the
+    multipliers are watched every iteration and a clamp re-runs the solve with every limit row in place (state word 114 = 4).  With the
+    action-mode impulse bound of 1e5 dt that does not happen in any other test (416 N s at dt = 1/240); here dt = 1e-3 (bound 100 N s)
+    and the arm joints are thrown at up to 400 rad/s every 8th step, which the motors cannot brake within their bound.  One-step
+    parity, resynchronised, must hold on that path too."""
+    torch = torch_mod
+    N = 64
+    kw = dict(dt=1e-3, residual_threshold=0.0)
+    o = oracle_mod.Oracle(N, seed=3, **kw); g = P.GpuProduct(N, seed=3, **kw); led = P.ConditionedParity(oracle_mod, slots=256, **kw)
+    rng = np.random.default_rng(0)
+    variants = np.zeros(6, int)
+    for t in range(96):
+        if t % 8 == 0:
+            a = np.c_[rng.uniform(-0.6, 0.6, N), rng.uniform(-0.8, -0.2, N), rng.uniform(0.05, 0.5, N), rng.uniform(0, 0.04, N)]
+            s = o.get_state(); s[:, 0:9] = REST; s[:, 9:16] = rng.uniform(-400, 400, (N, 7)); o.set_state(s)
+        P.sync_product(g, o); led.before(o)
+        o.step(a); g.step(a)
+        so = o.get_state(); sg = g.get_state()
+        np.testing.assert_array_equal(o.ncontacts(), sg[:, 106].astype(int))
+        led.after(o, a, np.abs(so[:, POS] - sg[:, POS]).max(1))
+        variants += np.bincount(sg[:, 114].astype(int), minlength=6)
+    print("clamped arm motors (dt = 1e-3): solver variants histogram", variants.tolist())
+    assert variants[4] > 50, "the re-run after a clamped arm motor row was not exercised: %s" % variants.tolist()
+    led.finish("clamped arm motors, re-run with limit rows", exempt_share=0.02, check_force=False)
 
 
 def test_joint_limit_rows_on_gpu(torch_mod, oracle_mod):
