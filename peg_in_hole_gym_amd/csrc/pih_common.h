@@ -153,6 +153,7 @@ constexpr int OVF_W_WORDS = 3 * (CMAX - CL) * WPS, OVF_REC_WORDS = (CMAX - CL) *
 // two-rows-per-lane row-space solver (11 .. HC contacts): columns KREG.. (the contact rows' columns) of its 128 x 128 matrix, [column][lane][2], streamed from L2
 constexpr int HC = 32, FR2 = NMOT + 3 * HC, KREG = NMOT, OVF_B_OFF = OVF_W_WORDS + OVF_REC_WORDS, OVF_B_WORDS = (FR2 - KREG) * 128, OVF_MW_OFF = OVF_B_OFF + OVF_B_WORDS, OVF_MW_WORDS = PIH_OBJ_NJ * 64;
 constexpr int OVF_WORDS = OVF_MW_OFF + OVF_MW_WORDS;
+constexpr int OVF_PAD_WORDS = 256;   // slack behind the LAST env's scratch: pgs_rows2's column ring reads (never uses) up to 12 columns past the column area
 struct Ovf { real* base; };
 PIH_HD real* wp_row(Shared& sh, const Ovf& ov, int row) { return row < 3 * CL ? sh.b.Wp[row] : ov.base + (size_t)(row - 3 * CL) * WPS; }
 PIH_HD real* crec_of(Shared& sh, const Ovf& ov, int c) { return c < CL ? sh.b.crec[c] : ov.base + OVF_W_WORDS + (size_t)(c - CL) * CREC; }

@@ -408,8 +408,8 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
     HIPCHK(h, hipDeviceSynchronize());
     return 0;
   }
-  HIPCHK(h, hipMalloc(&h->ovf, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
-  HIPCHK(h, hipMemset(h->ovf, 0, (size_t)cfg->n_envs * OVF_WORDS * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->ovf, ((size_t)cfg->n_envs * OVF_WORDS + OVF_PAD_WORDS) * sizeof(float)));
+  HIPCHK(h, hipMemset(h->ovf, 0, ((size_t)cfg->n_envs * OVF_WORDS + OVF_PAD_WORDS) * sizeof(float)));
   if (cfg->schedule & 3) HIPCHK(h, hipMalloc(&h->order, (size_t)cfg->n_envs * sizeof(int)));
   if ((cfg->schedule & 3) == 2) {
     int cus = 0; HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));

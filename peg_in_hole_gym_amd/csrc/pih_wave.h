@@ -77,6 +77,55 @@ PIH_HD void commit_lane(real& x, real y, int g) {
 PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane must be wave-uniform): v_readlane_b32
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
+// One Gauss-Seidel row of the two-rows-per-lane solver (pgs_rows2) as ONE issue-ordered block:
+//     cand = med3(z, lo, hi);  dl = cand - lam;  sdl = dl[lane G];  lam[G] = cand[G];  zz += col * sdl   (both halves, v_pk_fma_f32)
+// (z: the half of zz the row lives in; G: its compile-time lane.)  A wave alone on its SIMD issues one instruction of ANY kind per
+// 4 cycles, so what a row costs is its instruction count -- s_nop, s_waitcnt and scalar bookkeeping included -- and the heaviest env
+// of a launch, which is what the launch waits for, runs this row 4 800 times per step.  Left to the scheduler a row came out as
+// med3, sub, (s_lshl, cndmask), s_nop, readlane, s_waitcnt, pk_fma, s_nop; here the hazards of the gfx940 family are covered by
+// instructions the row needs anyway: a VALU result is read by v_readlane one instruction later at the earliest (s_lshl_b64 sits
+// between), and the SGPR a v_readlane wrote is read by the FMA two instructions later at the earliest (v_cndmask and the normal row's
+// second v_readlane, or one s_nop in a friction row).  The broadcast travels through the fixed pair s[100:101] (an asm operand cannot
+// name the low half of a 64-bit scalar operand; the high half is never read: op_sel_hi 0 takes the low half for both products).
+// Normal row: also s0 = cand[G], the new normal multiplier the friction bounds follow.
+PIH_HD void gs_row2_normal(pk2& zz, real z, pk2 col, real lo, real hi, real& lam, int G, real& dl, real& s0) {
+  real cand; unsigned long long m;
+  __asm__ volatile("v_med3_f32 %0, %6, %7, %8\n\tv_sub_f32 %1, %0, %3\n\ts_lshl_b64 %4, 1, %10\n\tv_readlane_b32 s100, %1, %10\n\t"
+                   "v_cndmask_b32_e64 %3, %3, %0, %4\n\tv_readlane_b32 %2, %0, %10\n\tv_pk_fma_f32 %5, s[100:101], %9, %5 op_sel_hi:[0,1,1]"
+                   : "=&v"(cand), "=&v"(dl), "=&s"(s0), "+v"(lam), "=&s"(m), "+v"(zz) : "v"(z), "v"(lo), "v"(hi), "v"(col), "n"(G) : "scc", "s100", "s101");
+}
+// A row with bounds lo .. hi and no follower rows (the pipe motor rows)
+PIH_HD void gs_row2_bounded(pk2& zz, real z, pk2 col, real lo, real hi, real& lam, int G, real& dl) {
+  real cand; unsigned long long m;
+  __asm__ volatile("v_med3_f32 %0, %5, %6, %7\n\tv_sub_f32 %1, %0, %2\n\ts_lshl_b64 %3, 1, %9\n\tv_readlane_b32 s100, %1, %9\n\t"
+                   "v_cndmask_b32_e64 %2, %2, %0, %3\n\ts_nop 0\n\tv_pk_fma_f32 %4, s[100:101], %8, %4 op_sel_hi:[0,1,1]"
+                   : "=&v"(cand), "=&v"(dl), "+v"(lam), "=&s"(m), "+v"(zz) : "v"(z), "v"(lo), "v"(hi), "v"(col), "n"(G) : "scc", "s100", "s101");
+}
+// Friction row: bounds -h .. h.  (One block per row, not per pair as in pgs_rows: the second row would have to read the half of zz
+// the first one has just written, and an asm operand cannot name a half of a 64-bit operand -- a separate input operand is by
+// contract the value at entry.  The s_waitcnt for the row's streamed column sits between two blocks anyway.)
+PIH_HD void gs_row2_friction(pk2& zz, real z, pk2 col, real h, real& lam, int G, real& dl) {
+  real cand; unsigned long long m;
+  __asm__ volatile("v_med3_f32 %0, %5, -%6, %6\n\tv_sub_f32 %1, %0, %2\n\ts_lshl_b64 %3, 1, %8\n\tv_readlane_b32 s100, %1, %8\n\t"
+                   "v_cndmask_b32_e64 %2, %2, %0, %3\n\ts_nop 0\n\tv_pk_fma_f32 %4, s[100:101], %7, %4 op_sel_hi:[0,1,1]"
+                   : "=&v"(cand), "=&v"(dl), "+v"(lam), "=&s"(m), "+v"(zz) : "v"(z), "v"(h), "v"(col), "n"(G) : "scc", "s100", "s101");
+}
+// The same for the one-row-per-lane solver (pgs_rows): z += b * sdl with v_fmac_f32, the broadcast in any SGPR; the two friction rows
+// of a contact (Bullet runs both or neither) are one block, so that nothing is inserted between them.
+PIH_HD void gs_row1_normal(real& z, real b, real lo, real hi, real& lam, int G, real& dl, real& s0) {
+  real cand, sdl; unsigned long long m;
+  __asm__ volatile("v_med3_f32 %0, %6, %7, %8\n\tv_sub_f32 %1, %0, %4\n\ts_lshl_b64 %5, 1, %10\n\tv_readlane_b32 %2, %1, %10\n\t"
+                   "v_cndmask_b32_e64 %4, %4, %0, %5\n\tv_readlane_b32 %3, %0, %10\n\tv_fmac_f32 %6, %2, %9"
+                   : "=&v"(cand), "=&v"(dl), "=&s"(sdl), "=&s"(s0), "+v"(lam), "=&s"(m), "+v"(z) : "v"(lo), "v"(hi), "v"(b), "n"(G) : "scc");
+}
+PIH_HD void gs_row1_friction2(real& z, real b1, real b2, real h, real& lam, int G1, int G2, real& dl1, real& dl2) {
+  real cand, sdl; unsigned long long m;
+  __asm__ volatile("v_med3_f32 %0, %6, -%7, %7\n\tv_sub_f32 %1, %0, %4\n\ts_lshl_b64 %5, 1, %10\n\tv_readlane_b32 %3, %1, %10\n\t"
+                   "v_cndmask_b32_e64 %4, %4, %0, %5\n\ts_nop 0\n\tv_fmac_f32 %6, %3, %8\n\t"
+                   "v_med3_f32 %0, %6, -%7, %7\n\tv_sub_f32 %2, %0, %4\n\ts_lshl_b64 %5, 1, %11\n\tv_readlane_b32 %3, %2, %11\n\t"
+                   "v_cndmask_b32_e64 %4, %4, %0, %5\n\ts_nop 0\n\tv_fmac_f32 %6, %3, %9"
+                   : "=&v"(cand), "=&v"(dl1), "=&v"(dl2), "=&s"(sdl), "+v"(lam), "=&s"(m), "+v"(z) : "v"(h), "v"(b1), "v"(b2), "n"(G1), "n"(G2) : "scc");
+}
 template <int CTRL> PIH_HD real dpp_add(real x) {   // x + x[dpp-permuted lane]  (v_add_f32_dpp)
   return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
@@ -479,9 +528,13 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       for (int k = 0; k < PF; k++) { pa4[k] = *reinterpret_cast<const real4*>(sh.mrec[k]); pl4[k] = *reinterpret_cast<const real4*>(sh.lrec[k]); }
       // the arm rows and the pipe motor rows do not see each other (A[arm row][pipe motor row] = 0): two accumulators, two chains
       real za = z, zp = z;
+      // The 9 arm joint blocks are spread evenly over the 23 pipe motor rows (block k in front of row 23 k / 9): a pipe row is
+      // med3, sub, <1 wait state>, v_readlane, <2 wait states>, fmac, and the instructions of an arm block are what fills those slots
+      // (with all arm blocks up front the last 14 pipe rows ran with three s_nop slots each).  The two chains commute exactly.
 #pragma unroll
-      for (int j = 0; j < PIH_OBJ_NJ; j++) {
-        if (j < 9) {   // arm joint block: motor, lower limit, upper limit; y = dinv (J du) of the joint
+      for (int jp = 0; jp < PIH_OBJ_NJ; jp++) {
+        const int j = (jp * 9 + PIH_OBJ_NJ - 1) / PIH_OBJ_NJ;         // the arm block in front of pipe row jp, if 23 j / 9 == jp
+        if (j < 9 && (PIH_OBJ_NJ * j) / 9 == jp) {   // arm joint block: motor, lower limit, upper limit; y = dinv (J du) of the joint
           const real4 ca = pa4[j % PF], cl = pl4[j % PF];
           if (j + PF < 9) { pa4[j % PF] = *reinterpret_cast<const real4*>(sh.mrec[j + PF]); pl4[j % PF] = *reinterpret_cast<const real4*>(sh.lrec[j + PF]); }
           const real rh = ca.y, th = ca.z, lim = ca.w;
@@ -506,8 +559,8 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
             za += Bn[j] * dl;
           }
         }
-        // pipe motor row 9 + j: every lane clamps its own z, the row's lane supplies the step
-        const int g = 9 + j;
+        // pipe motor row 9 + jp: every lane clamps its own z, the row's lane supplies the step
+        const int g = 9 + jp;
         const real cand = med3_(zp, lbv, ubv);
         const real dlv = cand - lamr[g];
         const real sdl = rdlane(dlv, g);
@@ -519,35 +572,25 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       // contacts: normal, dir1, dir2 -- the friction bounds follow the normal multiplier; Bullet leaves the friction rows of an
       // unloaded contact alone: a wave-uniform branch (half of the listed contacts are unloaded; collapsing their bounds onto the
       // current multiplier instead -- branch-free, step 0 -- costs the 14 VALU of two rows for nothing: 263 k vs 247 k cycles at 8-10)
+      // (nc and angmask through scalars that are opaque at every contact: the loop-invariant exit / friction conditions would otherwise
+      //  be precomputed as 64-bit lane masks outside the iteration loop, spilled to VGPR lanes and read back with v_readlane in every
+      //  iteration -- or the loop given a run-time trip count.  One copy per iteration, "modified" in place: no instruction per contact)
+      int ncl = nc; unsigned am = angmask;
 #pragma unroll
       for (int c = 0; c < MERGED_CONTACTS; c++) {
-        // (nc and angmask through opaque scalars: the loop-invariant exit / friction conditions would otherwise be precomputed as
-        //  64-bit lane masks outside the iteration loop, spilled to VGPR lanes and read back with v_readlane in every iteration)
-        int ncl = nc; unsigned am = angmask;
         __asm__ volatile("" : "+s"(ncl), "+s"(am));
         if (c >= ncl) break;
         const int g0 = NMOT + 3 * c;
-        const real cn = med3_(z, lbv, ubv);
-        const real dn = cn - lam;
-        const real s0 = rdlane(cn, g0), sdn = rdlane(dn, g0);
-        if (CHECK) busy |= __ballot(absr(dn) > thr) & (1ull << g0);
-        commit(lam, cn, g0);
-        z += Bn[g0] * sdn;
-        const bool loaded = s0 > 0 || ((am >> c) & 1u);
-        if (loaded) {                                   // wave-uniform (Bullet leaves the friction rows of an unloaded contact alone)
+        real dl, s0;
+        gs_row1_normal(z, Bn[g0], lbv, ubv, lam, g0, dl, s0);
+        if (CHECK) busy |= __ballot(absr(dl) > thr) & (1ull << g0);
+        // wave-uniform branch on  s0 > 0 || weld row  (as integers, on the scalar unit: see pgs_rows2)
+        const int s0i = __builtin_bit_cast(int, s0), weld = (int)((am >> c) & 1u);
+        if ((s0i > weld ? s0i : weld) > 0) {
           const real hi = max_(cmu * s0, cfl);
-          const real c1 = med3_(z, -hi, hi);
-          const real d1 = c1 - lam;
-          const real sd1 = rdlane(d1, g0 + 1);
-          if (CHECK) busy |= __ballot(absr(d1) > thr) & (1ull << (g0 + 1));
-          commit(lam, c1, g0 + 1);
-          z += Bn[g0 + 1] * sd1;
-          const real c2 = med3_(z, -hi, hi);
-          const real d2 = c2 - lam;
-          const real sd2 = rdlane(d2, g0 + 2);
-          if (CHECK) busy |= __ballot(absr(d2) > thr) & (1ull << (g0 + 2));
-          commit(lam, c2, g0 + 2);
-          z += Bn[g0 + 2] * sd2;
+          real dl2;
+          gs_row1_friction2(z, Bn[g0 + 1], Bn[g0 + 2], hi, lam, g0 + 1, g0 + 2, dl, dl2);
+          if (CHECK) busy |= (__ballot(absr(dl) > thr) & (1ull << (g0 + 1))) | (__ballot(absr(dl2) > thr) & (1ull << (g0 + 2)));
         }
       }
       return CHECK && busy == 0;
@@ -596,21 +639,13 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
   const int lane = w.lane();
   constexpr int D = 12;                                    // ring depth (columns in flight)
   real* const Bg = ov.base + OVF_B_OFF + 2 * lane;         // this lane's slot of streamed column s: Bg[s * 128 .. +1]
-  // one streamed column (both rows of the lane) = one 8-byte buffer load: lane * 8 in the vector offset, the column in the SCALAR
-  // offset (no 64-bit address arithmetic in vector registers).  The column index is clamped and made opaque at every use: otherwise
-  // the loop-invariant indices / addresses of all 84 columns are hoisted out of the iteration loop and spilled.
-  struct F2 { real x, y; };
-  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(ov.base + OVF_B_OFF), 0, OVF_B_WORDS * 4, 0x00020000);
-  int nsm1 = NMOT + 3 * nc - KREG - 1;                    // last streamed column (>= 0: this solver runs for nc > 10)
-  auto ldcol = [&](int sidx, int l8) __attribute__((always_inline)) -> F2 {
-    int hi = nsm1;
-    __asm__ volatile("" : "+s"(hi));
-    sidx = sidx < hi ? sidx : hi;
-    // (two adjacent b32 loads, which the backend merges into one buffer_load_dwordx2: this toolchain's raw_buffer_load_b64 /
-    //  _b128 builtins are lowered to a single dword replicated into every element)
-    F2 r; r.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, l8, sidx * 512, 0));
-    r.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, l8 + 4, sidx * 512, 0)); return r;
-  };
+  // one streamed column (both rows of the lane) = one 8-byte load at  (uniform column pointer) + lane * 8: global_load_dwordx2 with the
+  // pointer in an SGPR pair and the column in the instruction's immediate offset.  The pointer is made opaque once per iteration
+  // (otherwise the addresses of all 96 columns are loop invariants: hoisted out of the iteration loop and spilled).  No clamp on the
+  // column index: the ring runs up to D columns past the last one written, inside the env's own scratch (the parked motor rows
+  // behind the column area and, for the last env of the batch, OVF_PAD_WORDS of slack), and those values are never used.
+  static_assert(OVF_MW_WORDS + OVF_PAD_WORDS >= D * 128, "the ring reads D columns past the streamed-column area");
+  const unsigned l8 = (unsigned)lane * 8u;
   // ---- rows of this lane: r0 = lane (motor row, or contact row lane - 32), r1 = 64 + lane (contact row 32 + lane)
   struct RowC { real di, rhs, thr, lb, ub, mu, fl, lam0; };
   auto rowconst = [&](int g) __attribute__((always_inline)) -> RowC {
@@ -715,8 +750,12 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
   __threadfence_block();                                     // the streamed columns: written above, read back by the same lane
   w.sync();
   // ---- solve (every limit row in place)
-  // (the arm joints' three multipliers -- motor, lower, upper limit -- sit in lanes 0..8 of lam0 / lamlo / lamhi)
-  real lam0 = c0.lam0, lam1 = c1.lam0, lamlo = 0, lamhi = 0, z0, z1;
+  // (the arm joints' three multipliers -- motor, lower, upper limit -- are wave-uniform values in registers, as in pgs_rows: the
+  //  register budget is set by pgs_rows, and three v_readlane + three lane commits per joint and iteration were the price of lanes)
+  real lam0 = c0.lam0, lam1 = c1.lam0, z0, z1;
+  real lam_a[9], lam_lo[9], lam_hi[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
   {
     real v0 = 0, v1 = 0;                                     // warm start: z = lambda + rhs - dinv (J du) (see pgs_rows)
     for (int c = 0; c < nc; c++) {
@@ -736,11 +775,14 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
     unsigned long long busy = 0;
     __asm__ volatile("" ::: "memory");
     // ring of streamed columns: the first D are requested before the motor rows
-    int l8 = lane * 8;
-    __asm__ volatile("" : "+v"(l8));                       // (opaque once per iteration: the "+ 4" of the second word stays an immediate offset)
+    typedef const char __attribute__((address_space(1)))* gcp;
+    typedef const pk2 __attribute__((address_space(1)))* gpp;
+    gcp colp = (gcp)(ov.base + OVF_B_OFF);
+    __asm__ volatile("" : "+s"(colp));
+    auto ldcol = [&](int sidx) __attribute__((always_inline)) -> pk2 { return *(gpp)(colp + (size_t)sidx * 512 + l8); };
     pk2 rr[D];
 #pragma unroll
-    for (int s = 0; s < D; s++) { const F2 t = ldcol(s, l8); rr[s] = pk_pack(t.x, t.y); }
+    for (int s = 0; s < D; s++) rr[s] = ldcol(s);
     constexpr int PF = 2;
     real4 pa4[PF], pl4[PF];
 #pragma unroll
@@ -754,68 +796,63 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
         const real rh = ca.y, th = ca.z, lim = ca.w;
         const real lor = cl.x, hir = cl.y, wd = cl.w;
         real y = -rdlane(za, j);
-        const real la = rdlane(lam0, j), ll = rdlane(lamlo, j), lh = rdlane(lamhi, j);
-        real sum = la + (rh - y);
+        real sum = lam_a[j] + (rh - y);
         sum = med3_(sum, -lim, lim);
-        const real dl = sum - la; commit(lam0, sum, j);
+        const real dl = sum - lam_a[j]; lam_a[j] = sum;
         if (CHECK) busy |= __ballot(absr(dl) > th);
         y += dl * wd;
-        real s2 = ll + (lor - y); s2 = max_(s2, (real)0);
-        const real d2 = s2 - ll; commit(lamlo, s2, j);
+        real s2 = lam_lo[j] + (lor - y); s2 = max_(s2, (real)0);
+        const real d2 = s2 - lam_lo[j]; lam_lo[j] = s2;
         if (CHECK) busy |= __ballot(absr(d2) > th);
         y += d2 * wd;
-        real s3 = lh + (hir + y); s3 = max_(s3, (real)0);
-        const real d3 = s3 - lh; commit(lamhi, s3, j);
+        real s3 = lam_hi[j] + (hir + y); s3 = max_(s3, (real)0);
+        const real d3 = s3 - lam_hi[j]; lam_hi[j] = s3;
         if (CHECK) busy |= __ballot(absr(d3) > th);
         const real tot = dl + d2 - d3;
         za += pk_lo(BB[j]) * tot; zp1 = pk_pack(pk_lo(zp1), pk_hi(zp1) + pk_hi(BB[j]) * tot);
       }
       const int g = 9 + j;
-      const real cand = med3_(pk_lo(zp1), c0.lb, c0.ub);
-      const real dlv = cand - lam0;
-      const real sdl = rdlane(dlv, g);
+      real dlv;
+      gs_row2_bounded(zp1, pk_lo(zp1), BB[g], c0.lb, c0.ub, lam0, g, dlv);
       if (CHECK) busy |= __ballot(absr(dlv) > c0.thr) & (1ull << g);
-      commit(lam0, cand, g);
-      pk_fma(zp1, BB[g], sdl);
     }
     pk2 zz = pk_pack((za + pk_lo(zp1)) - z0, pk_hi(zp1));
-    // one row: clamp the lane's own z, take the row's step from its lane, move every z
-    auto rowstep = [&](int g, real lo0, real hi0, real lo1, real hi1, pk2 bb) __attribute__((always_inline)) -> real {
-      real cand, dlv;
-      if (g < 64) { cand = med3_(pk_lo(zz), lo0, hi0); dlv = cand - lam0; if (CHECK) busy |= __ballot(absr(dlv) > c0.thr) & (1ull << g); }
-      else { cand = med3_(pk_hi(zz), lo1, hi1); dlv = cand - lam1; if (CHECK) busy |= __ballot(absr(dlv) > c1.thr) & (1ull << (g - 64)); }
-      const real sdl = rdlane(dlv, g & 63);
-      const real sc = rdlane(cand, g & 63);
-      if (g < 64) commit(lam0, cand, g); else commit(lam1, cand, g - 64);
-      pk_fma(zz, bb, sdl);
-      return sc;
-    };
+    // one row (gs_row_normal / gs_row_friction): clamp the lane's own z, take the row's step from its lane, move every z
+    // (nc and angmask through scalars that are opaque at every contact: the 2 x 32 loop-invariant exit / friction conditions would
+    //  otherwise be precomputed as 64-bit lane masks outside the iteration loop and spilled, or the loop given a run-time trip count
+    //  and not unrolled.  One copy per iteration, modified "in place" by the empty asm: no instruction per contact)
+    int ncl = nc; unsigned am = angmask;
+    unsigned l8c = l8;
+    gcp colq = colp + D * 512;                               // column 3 c + D: what contact c requests
+    __asm__ volatile("" : "+s"(colq));
 #pragma unroll
     for (int c = 0; c < HC; c++) {
-      // (nc and angmask through opaque scalars: the 2 x 32 loop-invariant exit / friction conditions would otherwise be precomputed
-      //  as 64-bit lane masks outside the iteration loop and spilled to VGPR lanes)
-      int ncl = nc; unsigned am = angmask;
-      __asm__ volatile("" : "+s"(ncl), "+s"(am));
+      __asm__ volatile("" : "+s"(ncl), "+s"(am), "+v"(l8c));   // (l8c: its zero extension must be visible in the contact's own basic block
+                                                               //  for the scalar-base + 32-bit-lane-offset form of global_load)
       if (c >= ncl) break;
       const int g0 = NMOT + 3 * c;
       pk2 bb[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        const int i = g0 + k;
-        if (i < KREG) bb[k] = BB[i < KREG ? i : 0];
-        else {
-          const int s = i - KREG;
-          bb[k] = rr[s % D];
-          const F2 t = ldcol(s + D, l8);                    // request the column a ring ahead (clamped: a harmless reload at the end)
-          rr[s % D] = pk_pack(t.x, t.y);
-        }
+        const int sc = g0 + k - KREG;                        // (KREG = NMOT: every contact column is streamed)
+        bb[k] = rr[sc % D];
+        rr[sc % D] = *(gpp)(colq + k * 512 + l8c);         // request the column a ring ahead
       }
-      const real s0 = rowstep(g0, c0.lb, c0.ub, c1.lb, c1.ub, bb[0]);
-      const bool loaded = s0 > 0 || ((am >> c) & 1u);
-      if (loaded) {                                        // wave-uniform (Bullet leaves the friction rows of an unloaded contact alone)
-        const real h0 = max_(c0.mu * s0, c0.fl), h1 = max_(c1.mu * s0, c1.fl);
-        rowstep(g0 + 1, -h0, h0, -h1, h1, bb[1]);
-        rowstep(g0 + 2, -h0, h0, -h1, h1, bb[2]);
+      colq += 3 * 512;
+      __asm__ volatile("" : "+s"(colq));                   // (the running pointer stays in an SGPR pair: s_add_u32 / s_addc_u32 per contact)
+      real dl, s0;
+      if (g0 < 64) { gs_row2_normal(zz, pk_lo(zz), bb[0], c0.lb, c0.ub, lam0, g0, dl, s0); if (CHECK) busy |= __ballot(absr(dl) > c0.thr) & (1ull << g0); }
+      else { gs_row2_normal(zz, pk_hi(zz), bb[0], c1.lb, c1.ub, lam1, g0 - 64, dl, s0); if (CHECK) busy |= __ballot(absr(dl) > c1.thr) & (1ull << (g0 - 64)); }
+      // Bullet leaves the friction rows of an unloaded contact alone: wave-uniform branch on  s0 > 0 || weld row  -- as integers, on
+      // the scalar unit (the bit pattern of a positive float is a positive integer)
+      const int s0i = __builtin_bit_cast(int, s0), weld = (int)((am >> c) & 1u);
+      if ((s0i > weld ? s0i : weld) > 0) {
+        auto friction = [&](int g, pk2 col) __attribute__((always_inline)) {      // (row g lives in register set g / 64)
+          if (g < 64) { const real h0 = max_(c0.mu * s0, c0.fl); gs_row2_friction(zz, pk_lo(zz), col, h0, lam0, g, dl); if (CHECK) busy |= __ballot(absr(dl) > c0.thr) & (1ull << g); }
+          else { const real h1 = max_(c1.mu * s0, c1.fl); gs_row2_friction(zz, pk_hi(zz), col, h1, lam1, g - 64, dl); if (CHECK) busy |= __ballot(absr(dl) > c1.thr) & (1ull << (g - 64)); }
+        };
+        friction(g0 + 1, bb[1]);
+        friction(g0 + 2, bb[2]);
       }
     }
     z0 = pk_lo(zz); z1 = pk_hi(zz);
@@ -826,7 +863,9 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
   // ---- multipliers back to LDS, DOF velocities du = sum_i W_i lambda_i
   if (lane >= NMOT && lane < NMOT + 3 * nc) sh.r_lam[lane - NMOT] = lam0;
   if (32 + lane < 3 * nc) sh.r_lam[32 + lane] = lam1;
-  if (lane < NMOT) sh.mrec[lane][1] = lane < 9 ? lam0 + lamlo - lamhi : lam0;
+  if (lane >= 9 && lane < NMOT) sh.mrec[lane][1] = lam0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) if (lane == 0) sh.mrec[j][1] = lam_a[j] + lam_lo[j] - lam_hi[j];
   w.sync();
   {
     const int d = lane, dw = d < ND ? d : ND;
