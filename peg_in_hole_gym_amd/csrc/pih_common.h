@@ -50,6 +50,23 @@ PIH_CONST real L_HI[NL] = PIH_LINK_HI;
 PIH_CONST real L_DAMPING[NL] = PIH_LINK_DAMPING;
 PIH_CONST real L_MU[NL] = PIH_LINK_MU;
 PIH_CONST real ARM_BASE_R[9] = PIH_ARM_BASE_R;
+// Joint type and joint damping of a link WITHOUT a table load, for the wave-uniform serial sweeps (the ABA chains walk one link per step:
+// an s_load of L_JTYPE[L] / L_DAMPING[L] sat on the critical path of every link).  The structure of the generated model is asserted, so a
+// different model fails to compile instead of running with the wrong joint types: arm joints 0..6 revolute, the two fingers prismatic,
+// the pipe root floating, every other pipe link revolute; no joint damping anywhere.
+namespace model_ce {
+constexpr int JT[NL] = PIH_LINK_JTYPE;
+constexpr double DAMP[NL] = PIH_LINK_DAMPING;
+constexpr bool structure_ok() {
+  for (int L = 0; L < NL; L++) {
+    const int want = L < 7 ? PIH_JT_REVOLUTE : (L < ANL ? PIH_JT_PRISMATIC : (L == ANL ? PIH_JT_FLOATING : PIH_JT_REVOLUTE));
+    if (JT[L] != want || DAMP[L] != 0.0) return false;
+  }
+  return true;
+}
+static_assert(ANL == 9 && structure_ok(), "joint_type() below restates the structure of PIH_LINK_JTYPE / PIH_LINK_DAMPING");
+}
+PIH_HD int joint_type(int L) { return L < 7 ? PIH_JT_REVOLUTE : (L < ANL ? PIH_JT_PRISMATIC : (L == ANL ? PIH_JT_FLOATING : PIH_JT_REVOLUTE)); }
 PIH_CONST real EE_R[9] = PIH_EE_R;
 PIH_CONST real EE_T[3] = PIH_EE_T;
 PIH_CONST real ARM_REST[9] = PIH_ARM_REST;

@@ -58,7 +58,7 @@ template <class W> PIH_HD void aba(W& w, Shared& sh) {
       c.a = ld3(sh.LA[L]); c.u = sh.Au[L]; c.Di = sh.ADinv[L]; return c;
     };
     auto olink = [&](int L, const Acc& par, const OC& c) __attribute__((always_inline)) -> Acc {
-      const int jt = L_JTYPE[L], d = link_dof(L);
+      const int jt = joint_type(L), d = link_dof(L);
       V3 aa = par.al + c.ca;
       V3 ll = par.ac + cross(par.al, c.r) + c.cl;
       real qdd = (c.u - dot(c.Ua, aa) - dot(c.Ul, ll)) * c.Di;

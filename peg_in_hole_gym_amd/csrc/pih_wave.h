@@ -255,7 +255,7 @@ PIH_HD void aba_inward(Wave& w, Shared& sh, areal* rootp) {
     // one link with a joint (steps 2-4): stores U, 1/D, u; returns the lane's entry of what is handed up to the parent (garbage for
     // the arm root, whose parent is the fixed world: `up` = false skips the translation)
     auto link = [&](int L, real m, bool up) __attribute__((always_inline)) -> real {
-      const int jt = L_JTYPE[L];
+      const int jt = joint_type(L);                                    // (no table load on the chain: pih_common.h)
       const int sb = jt == PIH_JT_REVOLUTE ? 0 : 3;
       const V3 a = ld3(sh.LA[L]);
       const real rA = m1 * sh.AR[L][kA], rB = m1 * sh.AR[L][kB], rG = m2 * sh.AR[L][j2], rK = m2 * sh.AR[L][j1];
@@ -265,7 +265,7 @@ PIH_HD void aba_inward(Wave& w, Shared& sh, areal* rootp) {
       const real Ui = sum8(m * sj);                                    // U_i = sum_k I^A[i][sb + k] a_k, in every lane of row i
       const real Uj = from_lane(Ui, 4 * sUj);
       const real D = a.x * rdlane(Ui, 8 * sb) + a.y * rdlane(Ui, 8 * (sb + 1)) + a.z * rdlane(Ui, 8 * (sb + 2));
-      const real tau = -L_DAMPING[L] * sh.u[link_dof(L)];
+      const real tau = 0;                                               // (-L_DAMPING[L] * u: no joint damping in the model, asserted in pih_common.h)
       const real u = tau - (a.x * rdlane(m, 8 * sb + 6) + a.y * rdlane(m, 8 * (sb + 1) + 6) + a.z * rdlane(m, 8 * (sb + 2) + 6));
       const real Di = (real)1 / D;
       if (j == 0 && i < 6) sh.AU[L][i] = Ui;

@@ -10,7 +10,9 @@ env = PihVecEnv(n, auto_reset=1, debug=2, max_episode_steps=2227, schedule=sched
 gen = torch.Generator(device="cuda").manual_seed(1234)
 for t in range(420):
     env.step(torch.rand(n, 4, device="cuda", generator=gen) * 2 - 1)
+dump = {}
 for rep in range(3):
+    prev_cnt = env.state()[:, 106].cpu().clone(); prev_var = env.state()[:, 114].cpu().clone()
     env.step(torch.rand(n, 4, device="cuda", generator=gen) * 2 - 1)
     d = env.debug().double().cpu()
     cnt = env.state()[:, 106].cpu()
@@ -19,6 +21,8 @@ for rep in range(3):
     hw = d[:, 946].long(); xcc = d[:, 947].long()
     simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
     base = t0.min(); t0 = (t0 - base) * 0.01; t1 = (t1 - base) * 0.01       # 100 MHz ticks -> microseconds
+    dump["dur%d" % rep] = (t1 - t0).numpy(); dump["cnt%d" % rep] = cnt.numpy(); dump["prev_cnt%d" % rep] = prev_cnt.numpy(); dump["prev_var%d" % rep] = prev_var.numpy(); dump["var%d" % rep] = env.state()[:, 114].cpu().numpy()
+    dump["t0_%d" % rep] = t0.numpy(); dump["t1_%d" % rep] = t1.numpy()
     span = float(t1.max()); dur = t1 - t0
     print("launch %d: span %.1f us; sum of wave durations / span = %.0f waves in flight on average (2048 slots); env durations mean %.0f max %.0f" % (
         rep, span, float(dur.sum()) / span, float(dur.mean()), float(dur.max())))
@@ -55,3 +59,7 @@ for rep in range(3):
     print("   end times: p50 %.0f p90 %.0f p99 %.0f max %.0f" % (float(te[int(.5 * n)]), float(te[int(.9 * n)]), float(te[int(.99 * n)]), float(te[-1])))
     late = torch.argsort(t1)[-8:]
     print("   last 8 waves to end: contacts", [int(cnt[i]) for i in late], "start", [int(t0[i]) for i in late], "dur", [int(dur[i]) for i in late])
+
+import numpy as np
+os.makedirs("gpurun_out", exist_ok=True)
+np.savez("gpurun_out/sched_dur_%d.npz" % n, **dump)
