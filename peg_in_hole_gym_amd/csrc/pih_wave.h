@@ -70,6 +70,9 @@ PIH_HD void pk_fma(pk2& z, pk2 b, real s) {
   const pk2 s64 = (pk2)__builtin_bit_cast(unsigned, s);
   __asm__("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[0,1,1]" : "+v"(z) : "v"(b), "s"(s64));
 }
+// acc += J * w on both halves, w a wave-uniform value held in the LOW (pk_fma_lo) or HIGH (pk_fma_hi) half of the VGPR pair w2
+PIH_HD void pk_fma_lo(pk2& acc, pk2 j, pk2 w2) { __asm__("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(j), "v"(w2)); }
+PIH_HD void pk_fma_hi(pk2& acc, pk2 j, pk2 w2) { __asm__("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(j), "v"(w2)); }
 PIH_HD void commit_lane(real& x, real y, int g) {
   unsigned long long m;
   __asm__ volatile("s_lshl_b64 %1, 1, %3\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(x), "=&s"(m) : "v"(y), "n"(g) : "scc");   // s_lshl_b64 writes SCC
@@ -692,7 +695,7 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
 #pragma unroll
   for (int j = 0; j < PIH_OBJ_NJ; j++) Mg[j * 64] = mw.w[j];
   // ---- Jacobian rows (registers) of both rows of the lane
-  real J0[ND], J1[ND];
+  pk2 JJ[ND];                                              // (entry d of the row in register set 0, of the row in set 1)
   {
     auto geom = [&](int g, int& la, int& lb, V3& p, V3& dir, bool& ang, bool& live) __attribute__((always_inline)) {
       la = -1; lb = -1; p = mk(0, 0, 0); dir = mk(0, 0, 0); ang = false; live = false;
@@ -711,34 +714,64 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
     for (int d = 0; d < ND; d++) {
       const DofGeom g = gn;
       if (d + 1 < ND) gn = dof_geom(sh, d + 1);
-      J0[d] = lane < NMOT ? (d == md ? (real)1 : (real)0) : (l0 ? jac_entry(g, la0, lb0, p0, d0, a0) : (real)0);
-      J1[d] = l1 ? jac_entry(g, la1, lb1, p1, d1, a1) : (real)0;
-      __asm__ volatile("" : "+v"(J0[d]), "+v"(J1[d]) :: "memory");
+      real j0 = lane < NMOT ? (d == md ? (real)1 : (real)0) : (l0 ? jac_entry(g, la0, lb0, p0, d0, a0) : (real)0);
+      real j1 = l1 ? jac_entry(g, la1, lb1, p1, d1, a1) : (real)0;
+      __asm__ volatile("" : "+v"(j0), "+v"(j1) :: "memory");
+      JJ[d] = pk_pack(j0, j1);
     }
   }
   // contact columns: J . W_i, the response row W_i broadcast from LDS (contacts < CL) or from the env's scratch
   w.sync();
-#pragma unroll 1
-  for (int cb = 0; cb < HC; cb++) {                          // (rolled: the register-resident columns are handled by the switch below)
-    if (cb >= nc) break;
-    // the three response rows of the contact are requested together (they are contiguous, LDS or scratch): one round trip per contact
-    const real* wr = wp_row(sh, ov, 3 * cb);
-    real a0[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
+  // Both rows of the lane advance with one v_pk_fma_f32 per response-row entry; the entries are read in pairs (w_d, w_d+1) and the
+  // packed FMA picks the half (op_sel), so that the 228 FMAs + 114 reads of a contact become 114 + 57.  Two loops, because the rows of
+  // contacts < CL are LDS words and those of contacts >= CL global words: one loop over a generic pointer made every read a flat_load
+  // under a branch.  (Rows are 39 words apart: 4-byte aligned pairs, which ds_read2_b32 / global_load_dwordx2 accept.)
+  static_assert(ND % 2 == 0 && KREG == NMOT, "entries are consumed in pairs; every contact column is streamed");
+  auto column = [&](int cb, auto pairof) __attribute__((always_inline)) {
+    pk2 acc[3] = {0, 0, 0};
+    // (blocks of 4 DOFs = 6 pairs, requested one block ahead of their use: left alone the scheduler, at the register limit, issues
+    //  each read right in front of its FMA -- 57 serialised LDS round trips per contact)
+    constexpr int NB = (ND + 3) / 4;
+    pk2 wq[2][6];
+    auto request = [&](int blk, pk2* q) __attribute__((always_inline)) {
 #pragma unroll
-    for (int d = 0; d < ND; d++) {
+      for (int h = 0; h < 2; h++)
 #pragma unroll
-      for (int k = 0; k < 3; k++) { const real wv = wr[k * WPS + d]; a0[k] += J0[d] * wv; a1[k] += J1[d] * wv; }
+        for (int k = 0; k < 3; k++) { const int d = 4 * blk + 2 * h; q[3 * h + k] = d < ND ? pairof(k * WPS + d) : (pk2)0; }
+    };
+    request(0, wq[0]);
+#pragma unroll
+    for (int blk = 0; blk < NB; blk++) {
+      if (blk + 1 < NB) request(blk + 1, wq[(blk + 1) & 1]);
+      __asm__ volatile("" ::: "memory");                   // the next block's reads stay in front of this block's FMAs
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int d = 4 * blk + 2 * h;
+        if (d < ND) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) { pk_fma_lo(acc[k], JJ[d], wq[blk & 1][3 * h + k]); pk_fma_hi(acc[k], JJ[d + 1], wq[blk & 1][3 * h + k]); }
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int i = NMOT + 3 * cb + k;
-      const real b0 = (lane == i ? (real)1 : (real)0) - c0.di * a0[k], b1 = (64 + lane == i ? (real)1 : (real)0) - c1.di * a1[k];
-      if (i >= KREG) { Bg[(size_t)(i - KREG) * 128] = b0; Bg[(size_t)(i - KREG) * 128 + 1] = b1; }
-      else {
-        // register-resident column: static index through a fully unrolled select (i is wave-uniform)
-#pragma unroll
-        for (int q = NMOT; q < KREG; q++) if (q == i) BB[q] = pk_pack(b0, b1);
-      }
+      const real b0 = (lane == i ? (real)1 : (real)0) - c0.di * pk_lo(acc[k]), b1 = (64 + lane == i ? (real)1 : (real)0) - c1.di * pk_hi(acc[k]);
+      Bg[(size_t)(i - KREG) * 128] = b0; Bg[(size_t)(i - KREG) * 128 + 1] = b1;
+    }
+  };
+  {
+    const int nl = nc < CL ? nc : CL;
+#pragma unroll 1
+    for (int cb = 0; cb < nl; cb++) {
+      const real* wr = sh.b.Wp[3 * cb];
+      column(cb, [&](int o) __attribute__((always_inline)) { return pk_pack(wr[o], wr[o + 1]); });
+    }
+    typedef const real __attribute__((address_space(1)))* grp;
+#pragma unroll 1
+    for (int cb = CL; cb < nc; cb++) {
+      const grp wr = (grp)(ov.base + (size_t)(3 * (cb - CL)) * WPS);
+      column(cb, [&](int o) __attribute__((always_inline)) { return pk_pack(wr[o], wr[o + 1]); });
     }
   }
 #pragma unroll
