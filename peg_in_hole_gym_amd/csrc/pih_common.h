@@ -372,11 +372,15 @@ PIH_HD void tip_pose_serial(const real* S, real* out) {
   const int g = (int)S[PIH_S_GRASP];
   Q4 qq; qq.x = S[PIH_S_QUAT]; qq.y = S[PIH_S_QUAT + 1]; qq.z = S[PIH_S_QUAT + 2]; qq.w = S[PIH_S_QUAT + 3];
   M3 R = q_to_m(qq); V3 o = ld3(S + PIH_S_POS);
-  if (g != 0)
+  if (g != 0) {
+    // (unrolled: the link constants fold -- identity fixed rotations, unit axes -- instead of five scalar table loads on the chain of
+    //  every link; bounded-argument sin / cos as in the IK)
+#pragma unroll
     for (int L = ANL + 1; L < NL; L++) {
-      M3 Tl = mul(ldm(L_RFIX[L]), axis_angle(ld3(L_AXIS[L]), S[PIH_S_QJ + L - ANL - 1]));
+      M3 Tl = mul(ldm(L_RFIX[L]), axis_angle_joint(ld3(L_AXIS[L]), S[PIH_S_QJ + L - ANL - 1]));
       o = o + mul(R, ld3(L_TFIX[L])); R = mul(R, Tl);
     }
+  }
   V3 p = o + mul(R, mk(0, g == 0 ? (real)0.045 : (real)0.015, 0));
   Q4 q = m_to_q(R);
   out[0] = p.x; out[1] = p.y; out[2] = p.z; out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
