@@ -57,29 +57,23 @@ struct Wave {
   }
 };
 // ------------------------------------------------------------------------------------------------ cross-lane helpers
-// x[g] = y[g] for ONE lane g known at compile time.  The lane mask is made on the spot by the scalar unit (s_lshl_b64 of inline
-// constants): as a 64-bit constant operand it would be hoisted out of the solver loop, one SGPR pair per row, and spilled.
-// two floats in one 64-bit VGPR pair and z += b * s on both halves in ONE instruction (v_pk_fma_f32, s a wave-uniform scalar).  Written
+// Two floats in one 64-bit VGPR pair, so that z += b * s moves both halves in ONE instruction (v_pk_fma_f32, s a wave-uniform scalar:
+// gs_row2_* below).  Written
 // as asm on an integer container on purpose: with float2 vector types this toolchain emits the packed FMA but then reads the wrong
 // half of the pair in a following v_readlane (checked on the MI355X); the integer form extracts sub-registers correctly.
 typedef unsigned long long pk2;
 PIH_HD pk2 pk_pack(real x, real y) { return (pk2)__builtin_bit_cast(unsigned, x) | ((pk2)__builtin_bit_cast(unsigned, y) << 32); }
 PIH_HD real pk_lo(pk2 v) { return __builtin_bit_cast(float, (unsigned)v); }
 PIH_HD real pk_hi(pk2 v) { return __builtin_bit_cast(float, (unsigned)(v >> 32)); }
-PIH_HD void pk_fma(pk2& z, pk2 b, real s) {
-  const pk2 s64 = (pk2)__builtin_bit_cast(unsigned, s);
-  __asm__("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[0,1,1]" : "+v"(z) : "v"(b), "s"(s64));
-}
 // acc += J * w on both halves, w a wave-uniform value held in the LOW (pk_fma_lo) or HIGH (pk_fma_hi) half of the VGPR pair w2
 PIH_HD void pk_fma_lo(pk2& acc, pk2 j, pk2 w2) { __asm__("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(j), "v"(w2)); }
 PIH_HD void pk_fma_hi(pk2& acc, pk2 j, pk2 w2) { __asm__("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(j), "v"(w2)); }
-PIH_HD void commit_lane(real& x, real y, int g) {
-  unsigned long long m;
-  __asm__ volatile("s_lshl_b64 %1, 1, %3\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(x), "=&s"(m) : "v"(y), "n"(g) : "scc");   // s_lshl_b64 writes SCC
-}
 PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane must be wave-uniform): v_readlane_b32
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
+// (x[G] = y[G] for ONE lane G known at compile time -- the "commit" of a row's multiplier -- is  s_lshl_b64 mask, 1, G ; v_cndmask :
+//  the lane mask is made on the spot by the scalar unit, as a 64-bit constant operand it would be hoisted out of the solver loop, one
+//  SGPR pair per row, and spilled.)
 // One Gauss-Seidel row of the two-rows-per-lane solver (pgs_rows2) as ONE issue-ordered block:
 //     cand = med3(z, lo, hi);  dl = cand - lam;  sdl = dl[lane G];  lam[G] = cand[G];  zz += col * sdl   (both halves, v_pk_fma_f32)
 // (z: the half of zz the row lives in; G: its compile-time lane.)  A wave alone on its SIMD issues one instruction of ANY kind per
@@ -505,7 +499,6 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
   real lam = 0, z = 0;
   int it = 0;
   // commit one lane of a per-lane register: x[g] = y[g] (the lane mask is a compile-time constant in an SGPR pair)
-  auto commit = [&](real& x, real y, int g) __attribute__((always_inline)) { commit_lane(x, y, g); };
   auto solve = [&](auto FULLTAG) __attribute__((always_inline)) -> bool {     // returns true if an arm motor row clamped
     constexpr bool FULL = decltype(FULLTAG)::value;
 #pragma unroll
@@ -631,8 +624,8 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
 
 // ---- the same solver with TWO rows per lane, for envs with 11 .. HC contacts (128 rows; a fifth of the env-steps of the benchmark
 // workload and every one of its slowest: their DOF-space blocks were what a launch of 4096 envs waited for).  Row g lives in lane
-// g % 64 of register set g / 64.  The 128 x 128 matrix no longer fits the register file: the columns of the motor rows and of the
-// first 10 contacts (KREG = 62) stay in registers, the others are written once per step to the env's scratch in global memory
+// g % 64 of register set g / 64.  The 128 x 128 matrix no longer fits the register file: the columns of the 32 motor rows (KREG = NMOT)
+// stay in registers, those of the contact rows are written once per step to the env's scratch in global memory
 // ([column][lane][2], 512 B per column, L2-resident) and streamed through a ring of D prefetched columns in every iteration --
 // the addresses do not depend on the solve, so the loads are issued a ring ahead and never sit on the row chain.
 // Motor columns come from the symmetry of the Delassus matrix, A[r][motor m] = W_r[dof(m)], without a dot product.
@@ -802,7 +795,6 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
     }
     z0 = c0.rhs + v0; z1 = c1.rhs + v1;
   }
-  auto commit = [&](real& x, real y, int g) __attribute__((always_inline)) { commit_lane(x, y, g); };
   auto iterate = [&](auto CHECKTAG) __attribute__((always_inline)) -> bool {
     constexpr bool CHECK = decltype(CHECKTAG)::value;
     unsigned long long busy = 0;
