@@ -422,7 +422,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       if (crow) a = wown[dm];
       else if (m < 9) { if (lane < 9) a = wma_row(sh, m)[lane]; }
       else if (lane >= 9 && lane < NMOT) a = wmp_row(sh, m - 9)[lane - 3];   // DOF of pipe motor lane: 15 + (lane - 9); row entries start at DOF 9
-      __asm__ volatile("" : "+v"(a) :: "memory");
+      if (m % 4 == 3) __asm__ volatile("" : "+v"(a) :: "memory");          // four LDS reads in flight, not one (and not all 32: spills)
       A[m] = a;
     }
   }
