@@ -646,8 +646,11 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
 #pragma unroll
         for (int s = PIH_ARM_PIPE_SPH0; s < PIH_ARM_NSPH; s++) {
           const V3 d = sp - ld3(sh.a.ASP[s]);
-          const real dist = norm(d), dep = dist - r - ASPH_R[s];
-          if (dep < depth && dist > (real)1e-9) { depth = dep; bs = s; n = ((real)1 / dist) * d; valid = true; }
+          const real d2 = dot(d, d), reach = margin + r + ASPH_R[s];      // (depth <= margin: out of reach, out of the running)
+          if (d2 < reach * reach) {
+            const real dist = (real)sqrt(d2), dep = dist - r - ASPH_R[s];
+            if (dep < depth && dist > (real)1e-9) { depth = dep; bs = s; n = ((real)1 / dist) * d; valid = true; }
+          }
         }
         if (valid) { p = sp - (r + (real)0.5 * depth) * n; L = ANL + SAMP_LINK[i]; }
       }
@@ -673,9 +676,16 @@ template <class W> PIH_HD void collide(W& w, Shared& sh, const Params& P) {
         auto vtx = [&](int v) -> V3 { int si = v == 0 ? 0 : (v == 24 ? NSAMP - 1 : 7 + 5 * (v - 1)); return ld3(sh.a.SP[si]); };
         V3 p1 = vtx(s), q1 = vtx(s + 1), p2 = vtx(t), q2 = vtx(t + 1);
         V3 dm = (p1 + q1) - (p2 + q2);
-        if (dot(dm, dm) <= (real)(4 * 0.12 * 0.12)) {
-          V3 d1 = q1 - p1, d2 = q2 - p2, rr = p1 - p2;
-          real a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, rr), ss, tt;
+        // broad phase on the segment midpoints, exact for any geometry and margin: two segments closer than 2 r + margin have midpoints
+        // closer than that plus half of each length (dm = 2 x the midpoint difference).  With the fixed 12 cm of before, every pair two
+        // links apart (midpoints 11 cm apart on a straight pipe) went through the closest-point code; now a wave whose pairs are
+        // all out of reach skips it
+        V3 d1 = q1 - p1, d2 = q2 - p2;
+        real a = dot(d1, d1), e = dot(d2, d2);
+        const real reach = (real)sqrt(a) + (real)sqrt(e) + 2 * (2 * r + margin) + (real)1e-4;
+        if (dot(dm, dm) <= reach * reach) {
+          V3 rr = p1 - p2;
+          real f = dot(d2, rr), ss, tt;
           const real EPS = (real)1e-12;
           if (a <= EPS && e <= EPS) { ss = tt = 0; }
           else if (a <= EPS) { ss = 0; tt = clampr(f / e, 0, 1); }
