@@ -733,6 +733,7 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
   // contacts < CL are LDS words and those of contacts >= CL global words: one loop over a generic pointer made every read a flat_load
   // under a branch.  (Rows are 39 words apart: 4-byte aligned pairs, which ds_read2_b32 / global_load_dwordx2 accept.)
   static_assert(ND % 2 == 0 && KREG == NMOT, "entries are consumed in pairs; every contact column is streamed");
+  real wv0 = 0, wv1 = 0;                                     // warm start: sum over the contacts of (normal column) x (cached multiplier), see below
   auto column = [&](int cb, auto pairof) __attribute__((always_inline)) {
     pk2 acc[3] = {0, 0, 0};
     // (blocks of 4 DOFs = 6 pairs, requested one block ahead of their use: left alone the scheduler, at the register limit, issues
@@ -764,6 +765,7 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       const int i = NMOT + 3 * cb + k;
       const real b0 = (lane == i ? (real)1 : (real)0) - c0.di * pk_lo(acc[k]), b1 = (64 + lane == i ? (real)1 : (real)0) - c1.di * pk_hi(acc[k]);
       Bg[(size_t)(i - KREG) * 128] = b0; Bg[(size_t)(i - KREG) * 128 + 1] = b1;
+      if (k == 0) { const real l = sh.r_lam[3 * cb]; wv0 += b0 * l; wv1 += b1 * l; }   // (while the column is in registers: reading it back cost a round trip per contact)
     }
   };
   {
@@ -795,19 +797,7 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
   real lam_a[9], lam_lo[9], lam_hi[9];
 #pragma unroll
   for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
-  {
-    real v0 = 0, v1 = 0;                                     // warm start: z = lambda + rhs - dinv (J du) (see pgs_rows)
-    for (int c = 0; c < nc; c++) {
-      const int i = NMOT + 3 * c; const real l = sh.r_lam[3 * c];
-      real b0, b1;
-      if (i >= KREG) { b0 = Bg[(size_t)(i - KREG) * 128]; b1 = Bg[(size_t)(i - KREG) * 128 + 1]; }
-      else { b0 = 0; b1 = 0;
-#pragma unroll
-        for (int q = NMOT; q < KREG; q += 3) if (q == i) { b0 = pk_lo(BB[q]); b1 = pk_hi(BB[q]); } }
-      v0 += b0 * l; v1 += b1 * l;
-    }
-    z0 = c0.rhs + v0; z1 = c1.rhs + v1;
-  }
+  z0 = c0.rhs + wv0; z1 = c1.rhs + wv1;                      // warm start: z = lambda + rhs - dinv (J du) (see pgs_rows)
   auto iterate = [&](auto CHECKTAG) __attribute__((always_inline)) -> bool {
     constexpr bool CHECK = decltype(CHECKTAG)::value;
     unsigned long long busy = 0;
@@ -912,7 +902,18 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
     for (int j = 0; j < PIH_OBJ_NJ; j++) {
       du += Mg[j * 64] * (d < 9 ? (j < 9 ? sh.mrec[j][1] : (real)0) : sh.mrec[9 + j][1]);
     }
-    for (int r = 0; r < 3 * nc; r++) du += wp_row(sh, ov, r)[dw] * sh.r_lam[r];
+    // du += sum_r W_r[d] lambda_r: rows of contacts < CL from LDS, the others from the env's scratch -- two loops with known address
+    // spaces, four reads in flight (one loop over the generic row pointer was a serialised round trip per row, flat loads to global
+    // memory for the rows of contacts >= CL)
+    {
+      const int nl = 3 * (nc < CL ? nc : CL);
+#pragma unroll 8
+      for (int r = 0; r < nl; r++) du += sh.b.Wp[r][dw] * sh.r_lam[r];
+      typedef const real __attribute__((address_space(1)))* grp;
+      const grp wg = (grp)ov.base;
+#pragma unroll 4
+      for (int r = 3 * CL; r < 3 * nc; r++) du += wg[(size_t)(r - 3 * CL) * WPS + dw] * sh.r_lam[r];
+    }
     if (d < ND) sh.u[d] += du;
   }
   w.sync();
