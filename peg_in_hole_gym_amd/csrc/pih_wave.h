@@ -85,18 +85,21 @@ PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane mus
 // second v_readlane, or one s_nop in a friction row).  The broadcast travels through the fixed pair s[100:101] (an asm operand cannot
 // name the low half of a 64-bit scalar operand; the high half is never read: op_sel_hi 0 takes the low half for both products).
 // Normal row: also s0 = cand[G], the new normal multiplier the friction bounds follow.
-PIH_HD void gs_row2_normal(pk2& zz, real z, pk2 col, real lo, real hi, real& lam, int G, real& dl, real& s0) {
+// (A normal row's upper bound is PIH_BIG: its clamp is max(z, lo) -- TWO vector sources.  v_med3_f32 with three different VGPRs pays a
+//  register-bank conflict whenever the allocator puts two of them in one bank; with that clamp in every row, builds whose loops were
+//  instruction for instruction the same ran at 1 640 or 1 716 cycles per iteration.  The motor rows' bounds are symmetric: -hi, hi.)
+PIH_HD void gs_row2_normal(pk2& zz, real z, pk2 col, real lo, real& lam, int G, real& dl, real& s0) {
   real cand; unsigned long long m;
-  __asm__ volatile("v_med3_f32 %0, %6, %7, %8\n\tv_sub_f32 %1, %0, %3\n\ts_lshl_b64 %4, 1, %10\n\tv_readlane_b32 s100, %1, %10\n\t"
-                   "v_cndmask_b32_e64 %3, %3, %0, %4\n\tv_readlane_b32 %2, %0, %10\n\tv_pk_fma_f32 %5, s[100:101], %9, %5 op_sel_hi:[0,1,1]"
-                   : "=&v"(cand), "=&v"(dl), "=&s"(s0), "+v"(lam), "=&s"(m), "+v"(zz) : "v"(z), "v"(lo), "v"(hi), "v"(col), "n"(G) : "scc", "s100", "s101");
+  __asm__ volatile("v_max_f32 %0, %6, %7\n\tv_sub_f32 %1, %0, %3\n\ts_lshl_b64 %4, 1, %9\n\tv_readlane_b32 s100, %1, %9\n\t"
+                   "v_cndmask_b32_e64 %3, %3, %0, %4\n\tv_readlane_b32 %2, %0, %9\n\tv_pk_fma_f32 %5, s[100:101], %8, %5 op_sel_hi:[0,1,1]"
+                   : "=&v"(cand), "=&v"(dl), "=&s"(s0), "+v"(lam), "=&s"(m), "+v"(zz) : "v"(z), "v"(lo), "v"(col), "n"(G) : "scc", "s100", "s101");
 }
-// A row with bounds lo .. hi and no follower rows (the pipe motor rows)
-PIH_HD void gs_row2_bounded(pk2& zz, real z, pk2 col, real lo, real hi, real& lam, int G, real& dl) {
+// A row with symmetric bounds and no follower rows (the pipe motor rows)
+PIH_HD void gs_row2_bounded(pk2& zz, real z, pk2 col, real hi, real& lam, int G, real& dl) {      // bounds -hi .. hi
   real cand; unsigned long long m;
-  __asm__ volatile("v_med3_f32 %0, %5, %6, %7\n\tv_sub_f32 %1, %0, %2\n\ts_lshl_b64 %3, 1, %9\n\tv_readlane_b32 s100, %1, %9\n\t"
-                   "v_cndmask_b32_e64 %2, %2, %0, %3\n\ts_nop 0\n\tv_pk_fma_f32 %4, s[100:101], %8, %4 op_sel_hi:[0,1,1]"
-                   : "=&v"(cand), "=&v"(dl), "+v"(lam), "=&s"(m), "+v"(zz) : "v"(z), "v"(lo), "v"(hi), "v"(col), "n"(G) : "scc", "s100", "s101");
+  __asm__ volatile("v_med3_f32 %0, %5, -%6, %6\n\tv_sub_f32 %1, %0, %2\n\ts_lshl_b64 %3, 1, %8\n\tv_readlane_b32 s100, %1, %8\n\t"
+                   "v_cndmask_b32_e64 %2, %2, %0, %3\n\ts_nop 0\n\tv_pk_fma_f32 %4, s[100:101], %7, %4 op_sel_hi:[0,1,1]"
+                   : "=&v"(cand), "=&v"(dl), "+v"(lam), "=&s"(m), "+v"(zz) : "v"(z), "v"(hi), "v"(col), "n"(G) : "scc", "s100", "s101");
 }
 // Friction row: bounds -h .. h.  (One block per row, not per pair as in pgs_rows: the second row would have to read the half of zz
 // the first one has just written, and an asm operand cannot name a half of a 64-bit operand -- a separate input operand is by
@@ -109,11 +112,11 @@ PIH_HD void gs_row2_friction(pk2& zz, real z, pk2 col, real h, real& lam, int G,
 }
 // The same for the one-row-per-lane solver (pgs_rows): z += b * sdl with v_fmac_f32, the broadcast in any SGPR; the two friction rows
 // of a contact (Bullet runs both or neither) are one block, so that nothing is inserted between them.
-PIH_HD void gs_row1_normal(real& z, real b, real lo, real hi, real& lam, int G, real& dl, real& s0) {
+PIH_HD void gs_row1_normal(real& z, real b, real lo, real& lam, int G, real& dl, real& s0) {
   real cand, sdl; unsigned long long m;
-  __asm__ volatile("v_med3_f32 %0, %6, %7, %8\n\tv_sub_f32 %1, %0, %4\n\ts_lshl_b64 %5, 1, %10\n\tv_readlane_b32 %2, %1, %10\n\t"
-                   "v_cndmask_b32_e64 %4, %4, %0, %5\n\tv_readlane_b32 %3, %0, %10\n\tv_fmac_f32 %6, %2, %9"
-                   : "=&v"(cand), "=&v"(dl), "=&s"(sdl), "=&s"(s0), "+v"(lam), "=&s"(m), "+v"(z) : "v"(lo), "v"(hi), "v"(b), "n"(G) : "scc");
+  __asm__ volatile("v_max_f32 %0, %6, %7\n\tv_sub_f32 %1, %0, %4\n\ts_lshl_b64 %5, 1, %9\n\tv_readlane_b32 %2, %1, %9\n\t"
+                   "v_cndmask_b32_e64 %4, %4, %0, %5\n\tv_readlane_b32 %3, %0, %9\n\tv_fmac_f32 %6, %2, %8"
+                   : "=&v"(cand), "=&v"(dl), "=&s"(sdl), "=&s"(s0), "+v"(lam), "=&s"(m), "+v"(z) : "v"(lo), "v"(b), "n"(G) : "scc");
 }
 PIH_HD void gs_row1_friction2(real& z, real b1, real b2, real h, real& lam, int G1, int G2, real& dl1, real& dl2) {
   real cand, sdl; unsigned long long m;
@@ -570,7 +573,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
         }
         // pipe motor row 9 + jp: every lane clamps its own z, the row's lane supplies the step
         const int g = 9 + jp;
-        const real cand = med3_(zp, lbv, ubv);
+        const real cand = med3_(zp, -ubv, ubv);              // (the motor rows' bounds are symmetric; two vector sources, see gs_row2_normal)
         const real dlv = cand - lamr[g];
         const real sdl = rdlane(dlv, g);
         if (CHECK) busy |= __ballot(absr(dlv) > thr) & (1ull << g);
@@ -591,7 +594,7 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
         if (c >= ncl) break;
         const int g0 = NMOT + 3 * c;
         real dl, s0;
-        gs_row1_normal(z, Bn[g0], lbv, ubv, lam, g0, dl, s0);
+        gs_row1_normal(z, Bn[g0], lbv, lam, g0, dl, s0);
         if (CHECK) busy |= __ballot(absr(dl) > thr) & (1ull << g0);
         // wave-uniform branch on  s0 > 0 || weld row  (as integers, on the scalar unit: see pgs_rows2)
         const int s0i = __builtin_bit_cast(int, s0), weld = (int)((am >> c) & 1u);
@@ -841,7 +844,7 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       }
       const int g = 9 + j;
       real dlv;
-      gs_row2_bounded(zp1, pk_lo(zp1), BB[g], c0.lb, c0.ub, lam0, g, dlv);
+      gs_row2_bounded(zp1, pk_lo(zp1), BB[g], c0.ub, lam0, g, dlv);
       if (CHECK) busy |= __ballot(absr(dlv) > c0.thr) & (1ull << g);
     }
     pk2 zz = pk_pack((za + pk_lo(zp1)) - z0, pk_hi(zp1));
@@ -869,8 +872,8 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       colq += 3 * 512;
       __asm__ volatile("" : "+s"(colq));                   // (the running pointer stays in an SGPR pair: s_add_u32 / s_addc_u32 per contact)
       real dl, s0;
-      if (g0 < 64) { gs_row2_normal(zz, pk_lo(zz), bb[0], c0.lb, c0.ub, lam0, g0, dl, s0); if (CHECK) busy |= __ballot(absr(dl) > c0.thr) & (1ull << g0); }
-      else { gs_row2_normal(zz, pk_hi(zz), bb[0], c1.lb, c1.ub, lam1, g0 - 64, dl, s0); if (CHECK) busy |= __ballot(absr(dl) > c1.thr) & (1ull << (g0 - 64)); }
+      if (g0 < 64) { gs_row2_normal(zz, pk_lo(zz), bb[0], c0.lb, lam0, g0, dl, s0); if (CHECK) busy |= __ballot(absr(dl) > c0.thr) & (1ull << g0); }
+      else { gs_row2_normal(zz, pk_hi(zz), bb[0], c1.lb, lam1, g0 - 64, dl, s0); if (CHECK) busy |= __ballot(absr(dl) > c1.thr) & (1ull << (g0 - 64)); }
       // Bullet leaves the friction rows of an unloaded contact alone: wave-uniform branch on  s0 > 0 || weld row  -- as integers, on
       // the scalar unit (the bit pattern of a positive float is a positive integer)
       const int s0i = __builtin_bit_cast(int, s0), weld = (int)((am >> c) & 1u);
