@@ -255,6 +255,7 @@ def main():
     ap.add_argument("--exit-check-stride", type=int, default=0, help="cadence of the PGS early-exit test: 0 = library default (16), 1 = Bullet's (every iteration)")
     ap.add_argument("--schedule", type=int, default=1, help="dispatch order: 1 longest-job-first (default), 0 env order, 2 partner-aware (experimental); +4: no wave priority for heavy envs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--force-collective", action="store_true", help="initialise the process group and run the per-step all-gather / barrier / all-reduce even at world size 1 (exercises the RCCL path of configs[3] on a 1-GPU box)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (1-GPU box, gloo backend)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / collective / JSON plumbing only, no env and no GPU (CPU test of the N>1 path)")
     args = ap.parse_args()
@@ -269,9 +270,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     use_gpu = not args.dry_run
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if args.share_device:
             local_rank = 0
         if use_gpu:
@@ -320,7 +323,7 @@ def main():
                       "exit_check_stride": int(c.exit_check_stride), "exit_check": "Bullet's cadence (every iteration)" if c.exit_check_stride <= 1 else
                       "sampled: iterations 1..4, 4 + %d k and the last" % c.exit_check_stride, "solver_path": int(c.solver_path)}
     local_obs = torch.zeros(n, odim, device=dev)
-    gathered = torch.empty(world * n, odim, device=dev) if world > 1 and not args.no_allgather else None
+    gathered = torch.empty(world * n, odim, device=dev) if dist is not None and not args.no_allgather else None
 
     def one_step(t):
         obs = env.step(actions[t % pool])[0] if env is not None else local_obs

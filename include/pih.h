@@ -96,7 +96,7 @@ typedef struct pih_config {
   int32_t max_episode_steps;  /* action mode: done after this many steps (2227) */
   int32_t auto_reset;         /* 1: finished envs are reset inside pih_step */
   int32_t enable_self_collision;
-  int32_t debug;              /* 1: fill the debug buffer each step */
+  int32_t debug;              /* 1: fill the debug buffer each step; roctx ranges "pih_step(...)" / "pih_reset" around the launches (when a roctx library is loadable) */
   int32_t schedule;           /* 1 (default): longest-job-first dispatch order from the previous step's contact counts; 0: block i = env i;
                                  2: longest-job-first with the lightest envs as SIMD partners of the heaviest (experimental);
                                  +4: do not raise the issue priority of the wavefronts of contact-heavy envs (measurement switch) */
@@ -142,12 +142,13 @@ int pih_destroy(pih_handle* h);
  * hard != 0 = resetSimulation + reload (envs/base_env.py:85-86, envs/peg_in_hole.py:227-274): like the reference, a hard reset draws a
  *   NEW scene -- every env keeps advancing its own RNG draw sequence (the reference keeps drawing from the global `random`); it only also
  *   clears the env's non-finite-reset count and invalid flag.
- * seed != 0: explicit replay -- the handle's base seed becomes `seed` (env seed = seed + 1000 + global env index) and the envs reset by
- *   this call restart their draw sequence from its beginning.  seed == 0: keep the seed and continue the sequence.
+ * seed != 0: explicit replay -- the handle's base seed becomes `seed` (env seed = seed + 1000 + global env index) and every env
+ *   restarts its draw sequence from its beginning; needs mask_dev = NULL (returns -2 otherwise: an unmasked env would keep its draw
+ *   counter on another seed's stream).  seed == 0: keep the seed and continue the sequence.
  * (The reference never seeds: envs/peg_in_hole.py:239-267 use the global `random`.) */
 int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, uint64_t seed, void* stream);
-/* new base seed for all later resets; the envs reset by the NEXT pih_reset call restart their draw sequence from its beginning
- * (same as passing `seed` to that call) */
+/* new base seed for all later resets; the NEXT pih_reset call restarts every env's draw sequence from its beginning (same as passing
+ * `seed` to that call: it must reset all envs, mask_dev = NULL, and returns -2 otherwise) */
 int pih_reseed(pih_handle* h, uint64_t seed);
 /* actions_dev float[n,4]; obs_dev float[n,5]; reward_dev float[n]; done_dev uint8[n]
  * (PIH_TASK_RANDOM_FLY: actions float[n,6], obs float[n,6]) */
@@ -163,7 +164,8 @@ int pih_ik_ur5(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev,
 /* wrist camera of PegInHole.render (envs/peg_in_hole.py:276-304; eye = link 11, looking straight down, fov 60, near 0.001,
  * far 1000; the reference uses 300 x 300): out_dev float[env_count, height, width, 4] = (OpenGL depth-buffer value, r, g, b)
  * for envs env_begin .. env_begin+env_count-1, from the CURRENT state.  RGB is a flat value per object (table 153, pipe and
- * hole 232, fingers 77, background 255, the reference's uint8 scale): TinyRenderer's shading is not reproduced.  out_dev must be 16-byte aligned. */
+ * hole 232, fingers 77, background 255, the reference's uint8 scale), unshaded; pih_render_ex adds TinyRenderer's ambient + diffuse
+ * terms.  out_dev must be 16-byte aligned. */
 int pih_render(pih_handle* h, float* out_dev, int width, int height, int env_begin, int env_count, void* stream);
 /* the same with options: flags = PIH_RENDER_SHADED multiplies the per-object RGB value by ambient + diffuse x max(0, n . l) of
  * TinyRenderer's default light (getCameraImage without light arguments; specular term and shadow map not reproduced) */

@@ -118,11 +118,14 @@ class Oracle:
         """same contract as pih_reset: hard = resetSimulation (a NEW scene like any reset); seed != 0 = explicit replay from that seed"""
         m = None
         if mask is not None:
+            if seed != 0 or getattr(self, "_reseeded", False):
+                raise ValueError("a new seed needs a reset of all envs (mask=None), as pih_reset")
             m = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._reseeded = False
         self.L.piho_reset_ex(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None, int(bool(hard_reset)), int(seed))
 
     def reseed(self, seed):
-        self.L.piho_reseed(self.h, int(seed))
+        self.L.piho_reseed(self.h, int(seed)); self._reseeded = True
 
     def step(self, actions):
         a = np.ascontiguousarray(actions, dtype=self.real).reshape(self.n, 4)

@@ -559,6 +559,7 @@ static void reset_env(piho_handle* h, int e) {
 void piho_reset_ex(piho_handle* h, const uint8_t* mask, int hard, uint64_t seed);
 void piho_reset(piho_handle* h, const uint8_t* mask) { piho_reset_ex(h, mask, 0, 0); }
 void piho_reset_ex(piho_handle* h, const uint8_t* mask, int hard, uint64_t seed) {
+  if (mask && (seed != 0 || h->rewind_pending)) return;   /* a new seed needs a reset of ALL envs: rejected, as pih_reset does (returns -2) */
   if (seed != 0) { h->cfg.seed = seed; h->rewind_pending = 1; }
   const int rewind = h->rewind_pending; h->rewind_pending = 0;
   for (int e = 0; e < h->cfg.n_envs; e++) if (!mask || mask[e]) {

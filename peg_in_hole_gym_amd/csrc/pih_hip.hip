@@ -2,6 +2,7 @@
 // gfx950 only; one wavefront (64 threads, one workgroup) per env; per-env scratch in LDS (struct pih::Shared).
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o libpih_hip.so pih_hip.hip   (see build.py)
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -285,6 +286,28 @@ __global__ void pih_fly_init_offsets_kernel(float* __restrict__ state, const flo
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// roctx ranges around the step / reset launches (tracing): only with pih_config.debug != 0, and through dlopen so
+// that the library has no link-time dependency on the profiler SDK -- without the roctx library the ranges are silently absent.
+struct Roctx {
+  int (*push)(const char*) = nullptr; int (*pop)() = nullptr; bool tried = false;
+  void load() {
+    if (tried) return;
+    tried = true;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* l = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!l) continue;
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(l, "roctxRangePushA")); pop = reinterpret_cast<int (*)()>(dlsym(l, "roctxRangePop"));
+      if (push && pop) return;
+      push = nullptr; pop = nullptr;
+    }
+  }
+};
+static Roctx g_roctx;
+struct RoctxRange {      // RAII: pushes when tracing is on for this handle and the library was found
+  bool on = false;
+  RoctxRange(bool enabled, const char* name) { if (enabled) { g_roctx.load(); if (g_roctx.push) { g_roctx.push(name); on = true; } } }
+  ~RoctxRange() { if (on) g_roctx.pop(); }
+};
 constexpr size_t EV_POOL = 1024;   // timing event triples kept before they are folded into the running sums
 struct EvTriple { hipEvent_t a, b, c; };
 struct pih_handle {
@@ -399,7 +422,8 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
     HIPCHK(h, hipMemcpy(*offd, offsets_host, (size_t)cfg->n_envs * 3 * sizeof(float), hipMemcpyHostToDevice));
   }
   if (h->fly) {
-    // (dynamic LDS beyond the default 64 KB limit: the per-lane contact rows of 64 envs are LANE_WORDS * 64 words = 92 KB of the CU's 160 KB)
+    // (dynamic LDS beyond the default 64 KB limit: the per-lane contact rows and candidate staging of 64 envs are LANE_WORDS * 64 words)
+    static_assert((size_t)fly::LANE_WORDS * 64 * sizeof(float) <= 160 * 1024, "the random-fly kernel's per-wave LDS exceeds a CU's 160 KB");
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
     const int nb64 = (cfg->n_envs + 63) / 64;
     hipLaunchKernelGGL(pih_fly_init_offsets_kernel, dim3(nb64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
@@ -446,7 +470,14 @@ int pih_create(const pih_config* cfg, const float* offsets_host, pih_handle** ou
 
 int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, uint64_t seed, void* stream) {
   if (!h) return -2;
+  // a new seed rewinds the draw sequences, and that must reach EVERY env of the handle: with a mask the unmasked envs would keep
+  // their draw counter on a different seed stream (neither a replay nor a continuation; round-3 review) -- rejected
+  if (mask_dev && (seed != 0 || h->rewind_pending)) {
+    h->err = "pih_reset: a new seed (seed != 0, or a pending pih_reseed) needs a reset of all envs (mask_dev = NULL)";
+    return -2;
+  }
   PIH_ENTER(h);
+  RoctxRange range(h->cfg.debug != 0, hard ? "pih_reset(hard)" : "pih_reset");
   if (seed != 0) { h->cfg.seed = seed; h->P.seed = seed; h->rewind_pending = true; }
   const int rewind = h->rewind_pending ? 1 : 0;
   h->rewind_pending = false;
@@ -463,6 +494,7 @@ int pih_reseed(pih_handle* h, uint64_t seed) {
 }
 
 static int launch_step(pih_handle* h, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t s) {
+  RoctxRange range(h->cfg.debug != 0, h->fly ? "pih_step(random-fly)" : "pih_step(peg-in-hole)");
   EvTriple* t = nullptr;
   if (h->timing > 0 && (h->timing_tick++ % (unsigned)h->timing) == 0) {
     if (h->ev_used == EV_POOL) { int r = drain_events(h); if (r) return r; }

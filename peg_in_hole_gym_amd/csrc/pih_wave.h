@@ -84,14 +84,19 @@ PIH_HD real rdlane(real v, int lane) {   // broadcast one lane's value (lane mus
 // between), and the SGPR a v_readlane wrote is read by the FMA two instructions later at the earliest (v_cndmask and the normal row's
 // second v_readlane, or one s_nop in a friction row).  The broadcast travels through the fixed pair s[100:101] (an asm operand cannot
 // name the low half of a 64-bit scalar operand; the high half is never read: op_sel_hi 0 takes the low half for both products).
-// Normal row: also s0 = cand[G], the new normal multiplier the friction bounds follow.
+// Normal row: also s0 = cand[G], the new normal multiplier the friction bounds follow.  INVARIANT (the compiler's hazard recognizer does
+// not look inside an asm block, so every block must be safe by itself): s0's v_readlane is the THIRD instruction of the block
+// -- one instruction after the v_max that produced cand, four before the block ends -- so the two wait states between a VALU write of
+// an SGPR and a VALU read of it have passed whatever the scheduler places right after the block (round-3 review: it used to be the
+// second-to-last instruction and relied on scalar compare / branch instructions happening to follow).  Order in a normal row:
+//     v_max cand ; v_sub dl ; v_readlane s0 <- cand ; v_readlane s100 <- dl ; s_lshl mask ; v_cndmask lam ; v_pk_fma (reads s100).
 // (A normal row's upper bound is PIH_BIG: its clamp is max(z, lo) -- TWO vector sources.  v_med3_f32 with three different VGPRs pays a
 //  register-bank conflict whenever the allocator puts two of them in one bank; with that clamp in every row, builds whose loops were
 //  instruction for instruction the same ran at 1 640 or 1 716 cycles per iteration.  The motor rows' bounds are symmetric: -hi, hi.)
 PIH_HD void gs_row2_normal(pk2& zz, real z, pk2 col, real lo, real& lam, int G, real& dl, real& s0) {
   real cand; unsigned long long m;
-  __asm__ volatile("v_max_f32 %0, %6, %7\n\tv_sub_f32 %1, %0, %3\n\ts_lshl_b64 %4, 1, %9\n\tv_readlane_b32 s100, %1, %9\n\t"
-                   "v_cndmask_b32_e64 %3, %3, %0, %4\n\tv_readlane_b32 %2, %0, %9\n\tv_pk_fma_f32 %5, s[100:101], %8, %5 op_sel_hi:[0,1,1]"
+  __asm__ volatile("v_max_f32 %0, %6, %7\n\tv_sub_f32 %1, %0, %3\n\tv_readlane_b32 %2, %0, %9\n\tv_readlane_b32 s100, %1, %9\n\t"
+                   "s_lshl_b64 %4, 1, %9\n\tv_cndmask_b32_e64 %3, %3, %0, %4\n\tv_pk_fma_f32 %5, s[100:101], %8, %5 op_sel_hi:[0,1,1]"
                    : "=&v"(cand), "=&v"(dl), "=&s"(s0), "+v"(lam), "=&s"(m), "+v"(zz) : "v"(z), "v"(lo), "v"(col), "n"(G) : "scc", "s100", "s101");
 }
 // A row with symmetric bounds and no follower rows (the pipe motor rows)
@@ -114,8 +119,8 @@ PIH_HD void gs_row2_friction(pk2& zz, real z, pk2 col, real h, real& lam, int G,
 // of a contact (Bullet runs both or neither) are one block, so that nothing is inserted between them.
 PIH_HD void gs_row1_normal(real& z, real b, real lo, real& lam, int G, real& dl, real& s0) {
   real cand, sdl; unsigned long long m;
-  __asm__ volatile("v_max_f32 %0, %6, %7\n\tv_sub_f32 %1, %0, %4\n\ts_lshl_b64 %5, 1, %9\n\tv_readlane_b32 %2, %1, %9\n\t"
-                   "v_cndmask_b32_e64 %4, %4, %0, %5\n\tv_readlane_b32 %3, %0, %9\n\tv_fmac_f32 %6, %2, %8"
+  __asm__ volatile("v_max_f32 %0, %6, %7\n\tv_sub_f32 %1, %0, %4\n\tv_readlane_b32 %3, %0, %9\n\tv_readlane_b32 %2, %1, %9\n\t"
+                   "s_lshl_b64 %5, 1, %9\n\tv_cndmask_b32_e64 %4, %4, %0, %5\n\tv_fmac_f32 %6, %2, %8"
                    : "=&v"(cand), "=&v"(dl), "=&s"(sdl), "=&s"(s0), "+v"(lam), "=&s"(m), "+v"(z) : "v"(lo), "v"(b), "n"(G) : "scc");
 }
 PIH_HD void gs_row1_friction2(real& z, real b1, real b2, real h, real& lam, int G1, int G2, real& dl1, real& dl2) {

@@ -11,7 +11,8 @@ from .envs.utils import env_offsets
 
 class ShardedVecEnv:
     def __init__(self, total_envs, offset=(0, 0, 0), gather_obs=True, backend_factory=None, device=None, **cfg):
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._dist = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self._dist else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         if total_envs % self.world:
             raise ValueError("total_envs (%d) must be a multiple of the world size (%d)" % (total_envs, self.world))
@@ -25,7 +26,11 @@ class ShardedVecEnv:
                                      offsets=offs, env_index0=self.env0, **cfg)
         else:
             self.backend = backend_factory(self.n_local, offs, env_index0=self.env0, **cfg)
-        self.gather_obs = gather_obs and self.world > 1
+        # gather_obs: True = all-gather when there is more than one rank; 'always' = also at world size 1 (a process group must be
+        # initialised): the collective path of BASELINE configs[3] exercised on a single GPU; False = obs stay sharded
+        if gather_obs == "always" and not self._dist:
+            raise ValueError("gather_obs='always' needs an initialised torch.distributed process group")
+        self.gather_obs = bool(gather_obs) and (self.world > 1 or gather_obs == "always")
         self._gathered = None
 
     def reset(self, mask=None):

@@ -111,6 +111,43 @@ class PihVecEnv:
         with torch.cuda.device(self.device):
             self._chk(self.L.pih_set_state(self.h, _lib.FIELD_STATE, s.data_ptr(), self._stream()), "pih_set_state")
 
+    # --- checkpoint / resume: everything a handle owns is its per-env state record -- the 98 physical words incl. the
+    # RNG draw counters and step counters, the derived outputs, the warm-start contact cache -- plus the base seed; the config rides
+    # along so that a checkpoint is only loaded into a handle that simulates the same thing.
+    _CFG_KEYS = ("n_envs", "env_index0", "mode", "task_id", "object_id", "solver_iters", "ik_iters", "max_episode_steps", "auto_reset",
+                 "enable_self_collision", "enable_arm_collision", "solver_path", "attach_ball", "exit_check_stride", "dt", "residual_threshold",
+                 "erp", "warmstart", "contact_margin", "linear_slop", "ik_damping", "ik_residual", "dv")
+
+    def state_dict(self):
+        """-> {'state': float32 [n, state_words] (host copy), 'seed': int, 'config': {...}, 'abi_version': int}"""
+        torch.cuda.synchronize(self.device)
+        return {"state": self.state().cpu(), "seed": int(self.cfg.seed), "abi_version": int(self.L.pih_abi_version()),
+                "config": {k: (float(getattr(self.cfg, k)) if isinstance(getattr(self.cfg, k), float) else int(getattr(self.cfg, k))) for k in self._CFG_KEYS}}
+
+    def load_state_dict(self, sd, strict=True):
+        """Resume: after this call the handle continues bit for bit like the one that produced `sd` (same later draws: the RNG counters
+        are part of the record; the base seed must be the handle's).  strict: refuse a checkpoint of another config."""
+        if int(sd["abi_version"]) != int(self.L.pih_abi_version()):
+            raise _lib.PihError("checkpoint written by ABI v%d, this library is v%d" % (sd["abi_version"], self.L.pih_abi_version()))
+        mine = self.state_dict()["config"]
+        diff = {k: (v, mine[k]) for k, v in sd["config"].items() if k in mine and (abs(v - mine[k]) > 1e-9 * max(1.0, abs(v)))}
+        if strict and diff:
+            raise _lib.PihError("checkpoint / handle config mismatch: %s" % diff)
+        st = sd["state"]
+        if tuple(st.shape) != (self.n, self.state_words):
+            raise _lib.PihError("checkpoint state has shape %s, this handle %s" % (tuple(st.shape), (self.n, self.state_words)))
+        if int(sd["seed"]) != int(self.cfg.seed):       # (the base seed is fixed at creation: later auto-resets would draw other scenes)
+            raise _lib.PihError("checkpoint seed %d != handle seed %d: create the handle with seed=%d or use PihVecEnv.from_state_dict" % (sd["seed"], self.cfg.seed, sd["seed"]))
+        self.set_state(st)
+
+    @classmethod
+    def from_state_dict(cls, sd, device="cuda:0", offsets=None):
+        """A new handle with the checkpoint's config and seed, resumed from its state (offsets live in the state record)."""
+        cfg = dict(sd["config"]); n = int(cfg.pop("n_envs"))
+        env = cls(n, device=device, offsets=offsets, seed=int(sd["seed"]), **cfg)
+        env.load_state_dict(sd)
+        return env
+
     def ee_position(self):
         """World position of the grasp-target frame (pybullet link 11) after the last step / reset."""
         return self._get(_lib.FIELD_EE_POS, (self.n, 3))

@@ -12,10 +12,16 @@ env-step from copies of the input state perturbed by random relative errors of 1
 intermediate results and of its accumulation over 50 sweeps); the env-step is ILL-CONDITIONED when any probe deviates from the
 unperturbed oracle result by more than AMP = 30 times its perturbation.  This classification never looks at the product.  Asserted:
         well-conditioned env-steps (all but a few tenths of a percent):   error <= NORTH = 1e-3 m / rad, the north_star tolerance, as a MAX
-        ill-conditioned env-steps:                                        error <= 1.5 (the state stays sane), and their share is bounded
+        ill-conditioned env-steps:   error <= max(NORTH, K_SPREAD x the largest deviation any of the oracle's own 32 probes showed on
+                                     THAT env-step), K_SPREAD = 10: the licence scales with the measured amplification -- an env-step
+                                     that amplifies 30-fold is held to ~3e-3, one that throws the pipe by 0.8 rad to 8.  The product's
+                                     error is one more draw from the heavy-tailed response the probes sample, so a FEW env-steps may
+                                     exceed 10 x the largest of 32 draws: they are counted and their share of ALL env-steps asserted
+                                     <= SPREAD_EXC = 1e-4 (+1 env-step); every error < 1.5 (the state stays sane: no NaN, no blow-up);
+                                     the share of ill-conditioned env-steps itself is asserted (`ill_share`, default = exempt_share)
 plus the DISTRIBUTION: the share of env-steps above WELL = 1e-4 (default < 1 %), the median and the 99th percentile of the rest.  An
 arbitrarily wrong env-step cannot hide: it is either bounded at 1e-3, or it sits on a step where the fp64 oracle amplifies a 1e-6
-perturbation more than 30-fold -- and those are counted."""
+perturbation more than 30-fold -- those are counted -- and there it is bounded by what the oracle itself does."""
 import numpy as np
 
 POS = [*range(0, 9), *range(18, 25), *range(31, 54)]      # position-like words of the state record (arm q, base pose, pipe q)
@@ -77,6 +83,7 @@ class ConditionedParity:
            led.after(A, a, perr, frel)         # perr [n]: max |position-word error|; frel [n] (optional): |dF| / (1 + |F|)
        and at the end  led.finish(name, ...)   # runs the probes for the suspects and asserts (see the module docstring)."""
     SUSPECT, WELL, NORTH, AMP, K, MAGS = 3e-5, 1e-4, 1e-3, 30.0, 16, (1e-6, 1e-5)
+    K_SPREAD, SPREAD_EXC = 10.0, 1e-4
     F_SUSPECT, F_WELL = 1e-3, 1e-2
 
     def __init__(self, oracle_mod, with_cache=True, slots=512, task="peg-in-hole", **cfg):
@@ -136,7 +143,7 @@ class ConditionedParity:
                 amp[i] = max(amp[i], d / mag); ampf[i] = max(ampf[i], df / mag); spread[i] = max(spread[i], d)
         return amp, ampf, spread
 
-    def finish(self, name, exempt_share=0.01, p50=5e-6, p99=2e-5, f_p50=1e-3, f_p99=1e-2, check_force=True):
+    def finish(self, name, exempt_share=0.01, p50=5e-6, p99=2e-5, f_p50=1e-3, f_p99=1e-2, check_force=True, ill_share=None):
         perr = np.concatenate(self.perr); frel = np.concatenate(self.frel)
         amp_s, ampf_s, spread_s = self._amplification()
         where = np.array([x[0] for x in self.sus], dtype=int)
@@ -152,9 +159,20 @@ class ConditionedParity:
                   name, len(perr), np.percentile(perr, 50), np.percentile(perr, 99), well_max, exempt.sum(), 100 * exempt.mean(), self.WELL, big.sum(), 100 * big.mean(), self.NORTH,
                   ill.sum(), 100 * ill.mean(), self.AMP, perr.max(), spread[np.argmax(perr)]))
         worst = np.argmax(np.where(ill, 0.0, perr))
+        # the ill-conditioned env-steps: bounded by what the oracle's own probes did THERE
+        ill_bound = np.maximum(self.NORTH, self.K_SPREAD * spread)
+        exc = ill & (perr > ill_bound)
+        ratio = perr[ill] / np.maximum(spread[ill], 1e-300)
+        print("   margin on the well-conditioned env-steps: max %.2e vs the bound %.0e (%.1fx); ill-conditioned: error / (oracle's largest probe deviation) p50 %.2f p90 %.2f p99 %.2f max %.1f; "
+              "%d env-steps (%.1e of all) above max(%.0e, %.0f x probe deviation), allowed %.0e + 1" % (
+                  well_max, self.NORTH, self.NORTH / max(well_max, 1e-300), *(np.percentile(ratio, [50, 90, 99]) if ill.any() else (0, 0, 0)), ratio.max() if ill.any() else 0.0,
+                  exc.sum(), exc.mean(), self.NORTH, self.K_SPREAD, self.SPREAD_EXC))
         assert well_max <= self.NORTH, "%s: pose error %.3e on a WELL-conditioned env-step (oracle amplification of a perturbation there: %.1f)" % (name, perr[worst], amp[worst])
         assert exempt.mean() < exempt_share, "%s: %.3f %% of the env-steps exceed %.0e" % (name, 100 * exempt.mean(), self.WELL)
+        assert ill.mean() < (exempt_share if ill_share is None else ill_share), "%s: %.3f %% of the env-steps are ill-conditioned" % (name, 100 * ill.mean())
         assert np.percentile(perr, 50) < p50 and np.percentile(perr[~exempt], 99) < p99      # (p99 over the env-steps within WELL)
+        assert exc.sum() <= self.SPREAD_EXC * len(perr) + 1, "%s: %d ill-conditioned env-steps exceed %.0f x the oracle's own largest probe deviation (worst: error %.3e, probes %.3e)" % (
+            name, exc.sum(), self.K_SPREAD, perr[exc].max(), spread[exc][np.argmax(perr[exc])])
         assert perr.max() < 1.5
         if check_force:
             fill = (ampf > self.AMP) | ill
@@ -163,22 +181,7 @@ class ConditionedParity:
                 np.percentile(frel, 50), np.percentile(frel, 99), frel[~fill].max(), fex.sum(), 100 * fex.mean(), self.F_WELL))
             assert frel[~fill].max() <= self.F_WELL, "%s: force error %.3e (relative) on a well-conditioned env-step" % (name, frel[~fill].max())
             assert fex.mean() < exempt_share and np.percentile(frel, 50) < f_p50 and np.percentile(frel[~fex], 99) < f_p99
-        return dict(perr=perr, exempt=exempt, spread=spread)
-
-
-def force_parity(fo, fg, skip=20, win=16, tol=1e-2):
-    """Contact-normal force of two un-resynchronised trajectories, fo / fg [steps, n] (oracle / product) ->
-    (max |df| of the 16-step mean, max instantaneous |df|, max instantaneous |df| AWAY FROM FORCE TRANSIENTS, share of such steps).
-    A transient = the ORACLE's own force jumps by more than `tol` from one step to the next (a listed contact becomes loaded /
-    unloaded): the two simulations pass such an event a fraction of a step apart, which shows as a single-step difference of the
-    order of the jump itself; everywhere else the instantaneous force must agree to the north_star's 1e-2 N."""
-    fo = np.asarray(fo); fg = np.asarray(fg)
-    d = (fo - fg)[skip:]
-    k = np.ones(win) / win
-    avg = np.stack([np.convolve(d[:, i], k, mode="valid") for i in range(d.shape[1])], 1)
-    jump = np.zeros_like(fo, dtype=bool); jump[1:] = np.abs(fo[1:] - fo[:-1]) > tol
-    calm = ~jump; calm[1:] &= ~jump[:-1]; calm[:-1] &= ~jump[1:]; calm[:skip] = False
-    return np.abs(avg).max(), np.abs(d).max(), np.abs(fo - fg)[calm].max(), calm[skip:].mean()
+        return dict(perr=perr, exempt=exempt, spread=spread, ill=ill, amp=amp)
 
 
 def defaults_one_step_check(name, oracle_mod, product, N, steps, seed=5, expect_variants=None, omp=True):
@@ -191,7 +194,7 @@ def defaults_one_step_check(name, oracle_mod, product, N, steps, seed=5, expect_
     led = ConditionedParity(oracle_mod, with_cache=True)
     rng = np.random.default_rng(8)
     dA, dB, itA, variants, oerr = [], [], [], [], []
-    flips = 0
+    flips = 0; flip_err = []
     for t in range(steps):
         a = rng.uniform(-1, 1, (N, 4))
         sync_product(product, A); sync_oracle(B, A); led.before(A)
@@ -199,10 +202,12 @@ def defaults_one_step_check(name, oracle_mod, product, N, steps, seed=5, expect_
         og, rg, dg = product.step(a)
         sa = A.get_state(); sg = product.get_state()
         # same contact sets and done flags -- except where a sample sphere sits within float rounding of the contact margin (or the tip of
-        # the success radius): such an env-step took another DISCRETE branch than the oracle; counted, bounded below, left out of the
-        # error statistics of this step
+        # the success radius): such an env-step took another DISCRETE branch than the oracle; counted, its raw pose error recorded and
+        # bounded at 1e-2 below, left out of the error statistics of this step
         same = (A.ncontacts() == sg[:, 106].astype(int)) & (np.asarray(dg).astype(bool) == do.astype(bool))
         flips += int((~same).sum())
+        if not same.all():
+            flip_err.append(np.abs(sa[~same][:, POS] - sg[~same][:, POS]).max(1))
         cf = A.contact_force()
         led.after(A, a, np.where(same, np.abs(sa[:, POS] - sg[:, POS]).max(1), 0.0), np.where(same, np.abs(sg[:, 105] - cf) / (1 + np.abs(cf)), 0.0))
         oerr.append(np.where(same, np.abs(np.asarray(og)[:, 2:] - oo[:, 2:]).max(1), 0.0))
@@ -211,8 +216,10 @@ def defaults_one_step_check(name, oracle_mod, product, N, steps, seed=5, expect_
     dA, dB, itA, variants, oerr = map(np.concatenate, (dA, dB, itA, variants, oerr))
     res = led.finish(name)
     perr, ok = res["perr"], ~res["exempt"]
-    print("   discrete-branch flips (contact count or done flag differs from the oracle's): %d of %d env-steps" % (flips, N * steps))
+    fe = np.concatenate(flip_err) if flip_err else np.zeros(0)
+    print("   discrete-branch flips (contact count or done flag differs from the oracle's): %d of %d env-steps, pose error there max %.2e" % (flips, N * steps, fe.max() if len(fe) else 0.0))
     assert flips <= 2e-5 * N * steps + 1
+    assert not len(fe) or fe.max() < 1e-2      # a contact at the edge of the margin carries almost no impulse: the flipped step stays close
     print("   early exit (oracle at Bullet's cadence < 50 iterations) in %.1f %% of the env-steps" % (100 * (itA < 50).mean()))
     print("   iterations: product - oracle(Bullet cadence) min/max %d / %d, != 0 in %.2f %% ; product - oracle(product's cadence) != 0 in %.3f %%, max |.| %d" % (
         dA.min(), dA.max(), 100 * (dA != 0).mean(), 100 * (dB != 0).mean(), np.abs(dB).max()))
@@ -232,3 +239,158 @@ def defaults_one_step_check(name, oracle_mod, product, N, steps, seed=5, expect_
     assert (dB != 0).mean() < 5e-3
     assert oerr[ok].max() < 1e-4                                                      # observation (ee position): north_star 1e-3
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The north_star's acceptance run AS WRITTEN (BASELINE.json): N envs, library defaults, random actions, 1 000
+# FREE-RUNNING steps from identical seeds (no resynchronisation), product vs the fp64 oracle at Bullet's exit cadence; per env the first
+# step at which the peg-tip position differs by more than 1e-3 m / the contact-normal force by more than 1e-2 N / the observation
+# (fingers, end effector: BASELINE.json's "obs L-inf") by more than 1e-3.  The rollout is
+# chaotic, so every implementation leaves the oracle's trajectory eventually; the YARDSTICKS say when an fp64 run of
+# the ORACLE ITSELF does, under the two perturbations no fp32-state implementation can avoid:
+#   Y1  the initial state rounded to fp32 once (sync_oracle(..., rounded=True)), free-running in fp64 afterwards
+#   Y2  the state record rounded to fp32 after EVERY step (what the product's 256-word HBM record does to it), Bullet's cadence
+#   Y3  as Y2 at the product's exit-test cadence (exit_check_stride = 16)
+# and under the perturbation that stands for fp32 ARITHMETIC (the product's one-step error against the oracle from identical inputs is
+# 6e-7 m at the median, 2.5e-6 at the 99th percentile -- tests/test_gpu_defaults.py; the probes of ConditionedParity use the same size):
+#   Y4  as Y3, and the 77 position / velocity words multiplied by 1 + 1e-6 U(-1, 1) after every step
+# In a chaotic rollout the time to leave a tolerance grows with log(tolerance / perturbation): Y2 / Y3 bound what ANY implementation
+# with an fp32 state record can reach, Y4 what one with fp32 arithmetic can.
+# Reference contract: envs/base_env.py:60-75 driven by env.action_space.sample() (README.md:44-50).
+QS = (1, 5, 10, 25, 50, 75, 90)
+
+
+def _first_exceed(err, tol):
+    """err [steps, n] -> first step index with err > tol per env, `steps` where it never happens"""
+    ex = err > tol
+    return np.where(ex.any(0), ex.argmax(0), err.shape[0])
+
+
+def _quantiles(first, steps):
+    return {"q%02d" % q: int(np.percentile(first, q)) for q in QS} | {"never_share": float((first >= steps).mean()), "min": int(first.min()), "mean": float(first.mean())}
+
+
+def round_state_fp32(B, rel=0.0, rng=None):
+    """fp64 oracle B: pass its state record and warm-start cache through fp32 (what the product's HBM record holds between steps);
+    rel > 0: also perturb the 77 position / velocity words by a relative rel * U(-1, 1)"""
+    s = B.get_state(); c = B.warm_cache()
+    if rel > 0:
+        s[:, :77] *= 1 + rel * rng.uniform(-1, 1, (s.shape[0], 77))
+    B.set_state(f32(s)); B.set_warm_cache(f32(c))
+
+
+def first_exceedance_run(oracle_mod, product, N, steps=1000, seed=5, action_seed=8, omp=True, yardsticks=("Y1", "Y2", "Y3", "Y4"), tol_pose=1e-3, tol_force=1e-2, progress=None):
+    """-> dict: per-env first-exceedance steps of the product and of every yardstick (pose, force), their quantiles, and the
+    maximum tip / obs difference over the env-steps BEFORE the first exceedance.  `product`: GpuProduct or tests/emul's host build,
+    constructed with the same seed, auto_reset as the oracle (library default: off)."""
+    A = oracle_mod.Oracle(N, omp=omp, seed=seed)
+    Y = {}
+    if "Y1" in yardsticks:
+        Y["Y1"] = oracle_mod.Oracle(N, omp=omp, seed=seed); sync_oracle(Y["Y1"], A, rounded=True)
+    if "Y2" in yardsticks:
+        Y["Y2"] = oracle_mod.Oracle(N, omp=omp, seed=seed); round_state_fp32(Y["Y2"])
+    if "Y3" in yardsticks:
+        Y["Y3"] = oracle_mod.Oracle(N, omp=omp, seed=seed, exit_check_stride=16); round_state_fp32(Y["Y3"])
+    if "Y4" in yardsticks:
+        Y["Y4"] = oracle_mod.Oracle(N, omp=omp, seed=seed, exit_check_stride=16); round_state_fp32(Y["Y4"])
+    prng = np.random.default_rng(4242)
+    # identical seeds: the product's reset state is the oracle's to fp32 rounding (tests: test_reset_matches_oracle)
+    s0 = A.get_state(); sp = product.get_state()
+    assert np.abs(sp[:, POS] - s0[:, POS]).max() < 1e-6
+    rng = np.random.default_rng(action_seed)
+    names = ["product", *Y]
+    perr = {k: np.zeros((steps, N)) for k in names}; ferr = {k: np.zeros((steps, N)) for k in names}; oerr = {k: np.zeros((steps, N)) for k in names}
+    ncs = np.zeros((steps, N), dtype=np.int16); fo = np.zeros((steps, N))
+    dones = np.zeros(N, dtype=bool)
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (N, 4))
+        oo, _, do = A.step(a); tipA = A.tip_pose()[:, :3]; fA = A.contact_force()
+        og, _, dg = product.step(a)
+        sg = product.get_state()
+        perr["product"][t] = np.abs(sg[:, 98:101] - tipA).max(1); ferr["product"][t] = np.abs(sg[:, 105] - fA)
+        oerr["product"][t] = np.abs(np.asarray(og) - oo).max(1)
+        for k, B in Y.items():
+            ob, _, _ = B.step(a)
+            oerr[k][t] = np.abs(ob - oo).max(1)
+            perr[k][t] = np.abs(B.tip_pose()[:, :3] - tipA).max(1); ferr[k][t] = np.abs(B.contact_force() - fA)
+            if k != "Y1":
+                round_state_fp32(B, 1e-6 if k == "Y4" else 0.0, prng)
+        ncs[t] = A.ncontacts(); fo[t] = fA; dones |= do.astype(bool)
+        if progress and (t + 1) % 100 == 0:
+            progress("step %d: product tip err p50 %.2e max %.2e; exceeded so far: %s" % (
+                t + 1, np.median(perr["product"][t]), perr["product"][t].max(), {k: int((perr[k][:t + 1] > tol_pose).any(0).sum()) for k in names}))
+    out = {"N": N, "steps": steps, "seed": seed, "tol_pose_m": tol_pose, "tol_force_N": tol_force, "episodes_ended": int(dones.sum()),
+           "mean_contacts": float(ncs.mean()), "max_contacts": int(ncs.max()), "pose": {}, "force": {}, "obs": {}, "first": {}}
+    for k in names:
+        fp = _first_exceed(perr[k], tol_pose); ff = _first_exceed(ferr[k], tol_force); fb = _first_exceed(oerr[k], tol_pose)
+        out["pose"][k] = _quantiles(fp, steps); out["force"][k] = _quantiles(ff, steps); out["obs"][k] = _quantiles(fb, steps)
+        out["first"][k] = {"pose": fp, "force": ff, "obs": fb}
+    fp = out["first"]["product"]["pose"]
+    before = np.arange(steps)[:, None] < fp[None, :]
+    out["product_max_tip_err_before_first_exceedance"] = float(perr["product"][before].max()) if before.any() else 0.0
+    fb = out["first"]["product"]["obs"]
+    before_o = np.arange(steps)[:, None] < fb[None, :]
+    out["product_max_obs_err_before_first_exceedance"] = float(oerr["product"][before_o].max()) if before_o.any() else 0.0
+    out["product_tip_err_p50_p99_before_first_exceedance"] = [float(np.percentile(perr["product"][before], q)) for q in (50, 99)] if before.any() else [0.0, 0.0]
+    out["env_steps_within_tolerance_share"] = {k: float((perr[k] <= tol_pose).mean()) for k in names}
+    # what the trajectory was doing when it left: contact count and the oracle's force at the product's first exceedance
+    left = fp < steps
+    out["contacts_at_first_exceedance_hist"] = np.bincount(ncs[np.minimum(fp, steps - 1)[left], np.nonzero(left)[0]], minlength=1).tolist()
+    return out
+
+
+class ForceLedger:
+    """Contact-normal force of two UN-RESYNCHRONISED trajectories (oracle / product), every step held to the north_star's 1e-2 N except
+    where the fp64 ORACLE ITSELF moves by more than that: for every step with |dF| > tol / 3 the oracle's step is re-run from 2 K copies
+    of ITS input state perturbed by relative 1e-6 / 1e-5 (the two simulations are not in the same state there: by then their
+    trajectories differ by ~1e-5 m); the step is a TRANSIENT when any probe's force deviates from the unperturbed one by more than tol (a
+    listed contact becomes loaded / unloaded: a 1e-5 m shift decides on which side of the step that happens).  Asserted: |dF| <= tol on every
+    non-transient step; |dF| <= K_SPREAD x the probes' largest force deviation on the transients; their share <= `transient_share`; the
+    16-step mean <= tol everywhere.  (Round 3 classified by the oracle's own force JUMP and allowed a flat 5e-2 N there.)
+        led.before(o); o.step(a); product.step(a); led.after(a, f_oracle, f_product)   ...   led.finish(name)"""
+    K, MAGS, K_SPREAD = 16, (1e-6, 1e-5), 10.0
+
+    def __init__(self, oracle_mod, tol=1e-2, slots=256, **cfg):
+        cfg.pop("omp", None); cfg.pop("seed", None)
+        self.probe = oracle_mod.Oracle(slots, omp=True, **cfg)
+        self.slots, self.tol = slots, tol
+        self.s0, self.c0, self.a, self.fo, self.fg = [], [], [], [], []
+        self.rng = np.random.default_rng(777)
+
+    def before(self, o):
+        self.s0.append(o.get_state()); self.c0.append(o.warm_cache())
+
+    def after(self, a, fo, fg):
+        self.a.append(np.asarray(a, dtype=np.float64).copy()); self.fo.append(np.asarray(fo, dtype=np.float64).copy()); self.fg.append(np.asarray(fg, dtype=np.float64).copy())
+
+    def finish(self, name, skip=0, win=16, transient_share=0.02):
+        fo, fg = np.array(self.fo), np.array(self.fg)
+        d = np.abs(fo - fg); d[:skip] = 0
+        k = np.ones(win) / win
+        avg = np.abs(np.stack([np.convolve((fo - fg)[skip:, i], k, mode="valid") for i in range(fo.shape[1])], 1)).max()
+        sus = np.argwhere(d > self.tol / 3)
+        fdev = np.zeros_like(d)
+        rows = [(i, mag) for i in range(len(sus)) for mag in self.MAGS for _ in range(self.K)]
+        for c0 in range(0, len(rows), self.slots):
+            ch = rows[c0:c0 + self.slots]
+            st = np.zeros((self.slots, 128)); st[:, 24] = 1; ac = np.zeros((self.slots, 4)); ca = np.zeros((self.slots, 97)); ca[:, 1:49] = -1
+            for j, (i, mag) in enumerate(ch):
+                t, e = sus[i]
+                s = self.s0[t][e].copy(); s[:77] *= 1 + mag * self.rng.uniform(-1, 1, 77)
+                st[j] = s; ac[j] = self.a[t][e]; ca[j] = self.c0[t][e]
+            self.probe.set_state(st); self.probe.set_warm_cache(ca); self.probe.step(ac)
+            fr = self.probe.contact_force()
+            for j, (i, mag) in enumerate(ch):
+                t, e = sus[i]
+                fdev[t, e] = max(fdev[t, e], abs(fr[j] - fo[t, e]))
+        trans = fdev > self.tol
+        calm_max = d[~trans].max()
+        worst = np.unravel_index(np.argmax(np.where(trans, 0, d)), d.shape)
+        over = trans & (d > np.maximum(self.tol, self.K_SPREAD * fdev))
+        print("%s: contact force, %d steps x %d envs free-running: |dF| max %.3e N on the %.2f %% of steps where the fp64 oracle's own force is stable under a 1e-6 / 1e-5 perturbation "
+              "(bound %.0e); %d transient steps (%.2f %%; the oracle's probes move by up to %.3e N there), |dF| max %.3e N on them; 16-step mean max %.3e N" % (
+                  name, d.shape[0], d.shape[1], calm_max, 100 * (~trans).mean(), self.tol, trans.sum(), 100 * trans.mean(), fdev.max(), d[trans].max() if trans.any() else 0.0, avg))
+        assert calm_max <= self.tol, "%s: |dF| = %.3e N at step %d env %d where the oracle's own probes move by only %.3e N" % (name, calm_max, worst[0], worst[1], fdev[worst])
+        assert not over.any(), "%s: |dF| exceeds %.0f x the oracle's own probe deviation on %d transient steps" % (name, self.K_SPREAD, over.sum())
+        assert trans.mean() <= transient_share and avg <= self.tol
+        return dict(calm_max=calm_max, transients=int(trans.sum()), avg=avg, inst_max=float(d.max()))

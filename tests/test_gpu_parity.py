@@ -242,23 +242,21 @@ def test_trajectory_parity_contact_stable(torch_mod, oracle_mod, bent):
         s = o.get_state(); s[:, 31:54] = 0; s[:, 20] = -0.04 + 1e-4; o.set_state(s)
     _to_gpu_state(torch, g, s)
     maxd = maxo = 0.0
-    fo, fg = [], []
+    led = P.ForceLedger(oracle_mod, slots=128, **kw)
     for t in range(1000):
         ph = 2 * np.pi * t / 500.0
         a = np.tile([p0[0] + 0.1 * np.sin(ph), p0[1] + 0.1 * np.cos(ph) - 0.1, p0[2] + 0.05 * np.sin(2 * ph), 0.02], (N, 1))
+        led.before(o)
         oo, _, _ = o.step(a)
         og, _, _ = g.step(torch.tensor(a, dtype=torch.float32))
         maxd = max(maxd, np.abs(o.tip_pose()[:, :3] - g.tip_pose().cpu().numpy()[:, :3]).max())
         maxo = max(maxo, np.abs(oo - og.cpu().numpy()).max())
-        fo.append(o.contact_force()); fg.append(g.contact_force().cpu().numpy().astype(np.float64))
-    f_avg, f_inst, f_calm, calm_share = P.force_parity(fo, fg)
-    print("trajectory parity bent=%s: tip %.3e m, force 16-step mean %.3e N, instantaneous %.3e N (%.3e N on the %.1f %% of steps away from force transients), obs %.3e" % (
-        bent, maxd, f_avg, f_inst, f_calm, 100 * calm_share, maxo))
-    assert maxd < 1e-3 and f_avg < 1e-2 and maxo < 1e-3, (maxd, f_avg, maxo)
-    # north_star's 1e-2 N on the instantaneous force wherever the oracle's own force does not jump by more than that from one step to
-    # the next; at such load / unload transients of a listed contact (the two simulations pass them a fraction of a step apart) the
-    # single-step difference is of the order of the jump and is bounded at 5e-2 N
-    assert f_calm < 1e-2 and calm_share > 0.9 and f_inst < 5e-2, (f_calm, calm_share, f_inst)
+        led.after(a, o.contact_force(), g.contact_force().cpu().numpy())
+    print("trajectory parity bent=%s: tip %.3e m, obs %.3e" % (bent, maxd, maxo))
+    # north_star's 1e-2 N on every step whose force the oracle's own probes find stable, 16-step mean everywhere; transients classified
+    # by probes and bounded by 10 x the probes' deviation (tests/parity_util.py ForceLedger)
+    led.finish("trajectory parity (exit test off) bent=%s" % bent)
+    assert maxd < 1e-3 and maxo < 1e-3, (maxd, maxo)
 
 
 def test_gpu_matches_host_emulation_of_same_source(torch_mod):

@@ -241,3 +241,20 @@ def test_hole_tube_contact_geometry(oracle_mod):
     # samples beyond the tube's ends see its rim: their normals tilt outwards along the axis and the gap grows
     outside = tube[np.abs(tube[:, 2] - hole[0]) > hl + 1e-6]
     assert (outside[:, 8] > 0.002).all() and (np.abs(outside[:, 5]) > 0).all()
+
+
+def test_new_seed_needs_a_full_reset_oracle(oracle_mod):
+    """the oracle mirrors pih_reset's rule: a new seed (seed != 0 or a pending reseed) together with a mask is refused"""
+    o = oracle_mod.Oracle(6, seed=4)
+    s0 = o.get_state().copy()
+    m = np.array([1, 0, 1, 0, 1, 0], dtype=np.uint8)
+    with pytest.raises(ValueError):
+        o.reset(m, seed=5)
+    o.reseed(5)
+    with pytest.raises(ValueError):
+        o.reset(m)
+    np.testing.assert_array_equal(o.get_state(), s0)
+    o.reset()
+    np.testing.assert_array_equal(o.get_state()[:, :91], oracle_mod.Oracle(6, seed=5).get_state()[:, :91])
+    o.reset(m)
+    assert (o.get_state()[m == 1][:, 92] > o.get_state()[m == 0][:, 92]).all()
