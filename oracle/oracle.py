@@ -24,6 +24,12 @@ def _config_type(real):
     return _Config
 
 
+def _variant_type(real):
+    class _Variant(C.Structure):
+        _fields_ = [("row_order", C.c_int32), ("friction_dirs", C.c_int32), ("mu_clamp", real), ("pipe_motor_impulse", real), ("row_impulse_cap", real), ("max_coord_vel", real)]
+    return _Variant
+
+
 Config = _config_type(C.c_double)      # piho_config of the fp64 (checker) builds
 ConfigF32 = _config_type(C.c_float)    # ... of the fp32 CPU-baseline build (PIHO_REAL=float)
 
@@ -108,6 +114,21 @@ class Oracle:
         if offsets is not None:
             off = np.ascontiguousarray(offsets, dtype=self.real).reshape(n_envs, 3)
         self.h = self.L.piho_create(C.byref(self.cfg), _dp(off) if off is not None else None)
+
+    def set_variant(self, **kw):
+        """structural variants of the restated solver (pih_oracle.h piho_variant; defaults = what the product implements)"""
+        V = _variant_type(C.c_float if self.real is np.float32 else C.c_double)
+        v = V(); self.L.piho_default_variant(C.byref(v))
+        for k, x in kw.items():
+            if not hasattr(v, k):
+                raise AttributeError(k)
+            setattr(v, k, x)
+        self.L.piho_set_variant(C.c_void_p(self.h), C.byref(v))
+
+    def debug_friction(self):
+        """(friction multipliers [n, CMAX, 2], number of clamped coordinate velocities [n]) of the last step"""
+        lt = np.zeros((self.n, CMAX, 2), self.real); nc = np.zeros(self.n, dtype=np.int32)
+        self.L.piho_debug_friction(C.c_void_p(self.h), _dp(lt), nc.ctypes.data_as(C.POINTER(C.c_int32))); return lt, nc
 
     def __del__(self):
         if getattr(self, "h", None):

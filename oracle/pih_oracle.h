@@ -66,6 +66,21 @@ typedef struct {
 
 typedef struct piho_handle piho_handle;
 
+/* STRUCTURAL variants of the restated solver (round 4: which [UNVERIFIED] reading of Bullet makes 1 env-step in 300 chaotic?  swept by
+ * tools/ill_conditioned_causes.py; the defaults are what the product implements and every parity test runs) */
+typedef struct {
+  int32_t row_order;             /* 0 (default): per contact normal, friction 1, friction 2; 1: all contact normals, then all friction rows */
+  int32_t friction_dirs;         /* 2 (default) or 1 (btPlaneSpace1's first tangent only) */
+  piho_real mu_clamp;            /* 10 (default): upper clamp of the combined friction coefficient */
+  piho_real pipe_motor_impulse;  /* 1 (default): max impulse of the pipe joints' load-time velocity motors */
+  piho_real row_impulse_cap;     /* 1e30 (default): upper bound of a contact normal row's accumulated impulse */
+  piho_real max_coord_vel;       /* 100 (default): clamp of every coordinate velocity after the solve */
+} piho_variant;
+void piho_default_variant(piho_variant* v);
+void piho_set_variant(piho_handle* h, const piho_variant* v);
+/* diagnostics of the last step: per env the friction multipliers [n, CMAX, 2] and the number of coordinate velocities that hit the clamp */
+void piho_debug_friction(const piho_handle* h, piho_real* lambda_t, int32_t* nclamped);
+
 void piho_default_config(piho_config* c);
 piho_handle* piho_create(const piho_config* c, const piho_real* offsets /* [n,3] or NULL */);
 void piho_destroy(piho_handle* h);

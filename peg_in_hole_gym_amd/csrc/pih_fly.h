@@ -116,7 +116,9 @@ PIH_HD S3 sym_of(const M3& a) { S3 r; r.xx = a.m[0]; r.yy = a.m[4]; r.zz = a.m[8
 struct SI { S3 A; M3 B; S3 C; };
 
 // One dt of one env.  S: the env's state record (a per-lane local array); mem: this lane's contact-row scratch.
-template <class Mem>
+// EXTERNAL_IK: the IK targets S[PIH_F_TARGET ..] of THIS step were already computed (pih_fly_pre_kernel: one env per quad of lanes,
+// pih_ikq.h); otherwise the step runs the IK itself, one env per lane (the host harness, and the GPU before round 4).
+template <bool EXTERNAL_IK = false, class Mem>
 PIH_HD void step_env(real* S, const Params& P, int env_global, const real* action, real* obs, real* reward, unsigned char* done, Mem mem, real* dbg) {
   const real dt = P.dt;
   const bool frozen = !P.autoreset && S[PIH_F_DONE] != 0;   // finished envs keep their last values (envs/base_env.py:62,66)
@@ -127,7 +129,10 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
 #pragma unroll
     for (int i = 0; i < NJ; i++) { q[i] = S[PIH_F_Q + i]; qd[i] = S[PIH_F_QD + i]; }
     real vt[NJ];
-    {
+    if constexpr (EXTERNAL_IK) {
+#pragma unroll
+      for (int i = 0; i < NJ; i++) vt[i] = (real)PIH_UR5_KP * (S[PIH_F_TARGET + i] - q[i]) / dt;
+    } else {
       Serial sw; real ikT[NJ][12]; real qs[NJ];
       const Q4 tq = quat_from_euler(action[3], action[4], action[5]);
       const V3 tp = mk(action[0] - S[PIH_F_OFFSET], action[1] - S[PIH_F_OFFSET + 1], action[2] - S[PIH_F_OFFSET + 2]);

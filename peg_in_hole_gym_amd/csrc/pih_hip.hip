@@ -21,9 +21,9 @@ using namespace pih;
 // late leaves most of the chip idle at the tail.  This single-workgroup counting sort orders the envs by the contact count
 // of their PREVIOUS step (descending); pih_step_kernel maps blockIdx through it.  Results do not depend on block order.
 // Launch 1 of a step.  Block 0: longest-job-first dispatch order (counting sort of the envs by their previous-step contact
-// count, most contacts first).  Blocks 1..: the controller (action / state machine -> IK -> joint targets), ONE ENV PER LANE
-// of the block's first wavefront (controller_targets is strictly sequential per env; as wave-uniform code inside the
-// one-wave-per-env step kernel it ran at 1/64 lane utilisation).  The two parts touch disjoint state words.
+// count, most contacts first).  Blocks 1..: the controller (action / state machine -> IK -> joint targets), ONE ENV PER QUAD OF LANES
+// (pih_ikq.h: 64 envs per block, 16 per wavefront; rounds 1-3 ran one env per lane: 64 wavefronts walking ~1 000 dependent instructions
+// per IK iteration -- the quad shortens that chain to ~600 on 256 wavefronts).  The two parts touch disjoint state words.
 constexpr int PRE_THREADS = 256;
 // sched_k > 0 (config.schedule = 2): "light seeds".  With n envs on m wave slots and n / m around 2, longest-job-first pairs the
 // heaviest env of the launch with the lightest one in the same slot -- the launch then ends a whole light env after the heaviest one.
@@ -54,14 +54,15 @@ __global__ void __launch_bounds__(PRE_THREADS) pih_pre_kernel(Params P, float* _
     }
     return;
   }
-  if (t >= 64) return;
-  const int env = (blockIdx.x - 1) * 64 + t;
-  if (env >= n) return;
+  // controller: one env per QUAD of lanes (pih_ikq.h), 64 envs per block = 4 wavefronts of 16 envs
+  const int env = (blockIdx.x - 1) * 64 + (t >> 2);
+  if (env >= n) return;                                   // (uniform per quad: DPP never reads a lane that has left)
   float* S = state + (size_t)env * PIH_STATE_WORDS;
   if (!P.autoreset && S[PIH_S_DONE] != 0) return;      // finished envs keep their last values (envs/base_env.py:62,66)
   float a[4] = {0, 0, 0, 0};
   if (actions) { a[0] = actions[env * 4]; a[1] = actions[env * 4 + 1]; a[2] = actions[env * 4 + 2]; a[3] = actions[env * 4 + 3]; }
-  controller_targets(S, P, a);
+  QuadDpp qd; qd.l = t & 3;
+  controller_targets_quad(qd, S, P, a);
 }
 
 __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __restrict__ state,
@@ -117,33 +118,28 @@ __global__ void __launch_bounds__(64) pih_init_offsets_kernel(float* __restrict_
   for (int k = 0; k < 3; k++) rec[PIH_S_OFFSET + k] = offsets ? offsets[3 * e + k] : 0.f;
 }
 
-// stand-alone batched IK (envs/utils.py:67,79): one problem per LANE (the solve is strictly sequential)
+// stand-alone batched IK (envs/utils.py:67,79): one problem per QUAD of lanes (pih_ikq.h), 16 problems per wavefront
+template <class C> __device__ __forceinline__ void ik_quad_problem(const Params& P, int n, int stride, const float* q0, const float* tpos, const float* tquat, float* qout) {
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 2);
+  if (i >= n) return;
+  QuadDpp qd; qd.l = threadIdx.x & 3;
+  const int j0 = 2 * qd.l, j1 = 2 * qd.l + 1;
+  const QuadSlots sl = ikq_slots<C>(qd);
+  float a = j0 < C::N ? q0[i * stride + j0] : 0.0f, b = j1 < C::N ? q0[i * stride + j1] : 0.0f;
+  Q4 tq; tq.x = tquat[4 * i]; tq.y = tquat[4 * i + 1]; tq.z = tquat[4 * i + 2]; tq.w = tquat[4 * i + 3];
+  ikq_solve(qd, sl, P, mk(tpos[3 * i], tpos[3 * i + 1], tpos[3 * i + 2]), tq, a, b);
+  if (j0 < C::N) qout[i * stride + j0] = a;
+  if (j1 < C::N) qout[i * stride + j1] = b;
+  for (int k = C::N + qd.l; k < stride; k += 4) qout[i * stride + k] = q0[i * stride + k];      // (Panda: the finger entries pass through)
+}
 __global__ void __launch_bounds__(64) pih_ik_kernel(Params P, int n, const float* __restrict__ q0, const float* __restrict__ tpos,
                                                     const float* __restrict__ tquat, float* __restrict__ qout) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  Serial sw; float ikT[7][12];
-  float q[9];
-  for (int k = 0; k < 9; k++) q[k] = q0[i * 9 + k];
-  Q4 tq; tq.x = tquat[4 * i]; tq.y = tquat[4 * i + 1]; tq.z = tquat[4 * i + 2]; tq.w = tquat[4 * i + 3];
-  float qs[7];
-  ik_chain<PandaChain>(sw, ikT, P, q, mk(tpos[3 * i], tpos[3 * i + 1], tpos[3 * i + 2]), tq, qs);
-  for (int k = 0; k < 7; k++) qout[i * 9 + k] = qs[k];
-  qout[i * 9 + 7] = q[7]; qout[i * 9 + 8] = q[8];
+  ik_quad_problem<PandaChain>(P, n, 9, q0, tpos, tquat, qout);
 }
-
 // the same for the UR5 chain (envs/utils.py:79): q0 float[n,6] -> qout float[n,6]
 __global__ void __launch_bounds__(64) pih_ik_ur5_kernel(Params P, int n, const float* __restrict__ q0, const float* __restrict__ tpos,
                                                         const float* __restrict__ tquat, float* __restrict__ qout) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  Serial sw; float ikT[6][12];
-  float q[6];
-  for (int k = 0; k < 6; k++) q[k] = q0[i * 6 + k];
-  Q4 tq; tq.x = tquat[4 * i]; tq.y = tquat[4 * i + 1]; tq.z = tquat[4 * i + 2]; tq.w = tquat[4 * i + 3];
-  float qs[6];
-  ik_chain<Ur5Chain>(sw, ikT, P, q, mk(tpos[3 * i], tpos[3 * i + 1], tpos[3 * i + 2]), tq, qs);
-  for (int k = 0; k < 6; k++) qout[i * 6 + k] = qs[k];
+  ik_quad_problem<Ur5Chain>(P, n, 6, q0, tpos, tquat, qout);
 }
 
 // wrist camera (p12): grid = (strips, envs), 256 threads (4 waves); out float[count, H, W, 4] = depth, r, g, b
@@ -225,6 +221,26 @@ __global__ void pih_gather_kernel(const float* __restrict__ state, float* __rest
 // (Measured on the MI355X, round 3, profiles/r03_fly_envs_per_wave.txt: packing FEWER envs into a wave -- 32 .. 4, i.e. 128 .. 1024
 //  waves for 4096 envs -- does not shorten the launch although the data-dependent PGS loop then waits for the slowest of fewer lanes,
 //  and from 512 waves on it lengthens it: the waves of a CU pair then contend for instruction fetch, SQ_WAIT_INST_ANY 2 % -> 52 %.)
+// Launch 1 of a random-fly step: the controller ur_execute (envs/utils.py:70-82) -- getQuaternionFromEuler + calculateInverseKinematics --
+// with one env per QUAD of lanes (pih_ikq.h); writes the IK targets into the state record (words PIH_F_TARGET .., structure-of-arrays).
+// 256 threads = 64 envs per block.  (Rounds 2-3 ran the IK inside the one-env-per-lane step kernel, where it was 60 % of the
+// instruction stream of 64 lone wavefronts.)
+__global__ void __launch_bounds__(256) pih_fly_pre_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions, int n) {
+  const int env = blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (env >= n) return;
+  if (!P.autoreset && state[(size_t)PIH_F_DONE * n + env] != 0) return;      // frozen (envs/base_env.py:62,66): targets stay
+  QuadDpp qd; qd.l = threadIdx.x & 3;
+  const int j0 = 2 * qd.l, j1 = j0 + 1;
+  const QuadSlots sl = ikq_slots<Ur5Chain>(qd);
+  float q0 = j0 < fly::NJ ? state[(size_t)(PIH_F_Q + j0) * n + env] : 0.0f, q1 = j1 < fly::NJ ? state[(size_t)(PIH_F_Q + j1) * n + env] : 0.0f;
+  const float* a = actions + (size_t)env * PIH_FLY_ACTION_DIM;
+  const Q4 tq = quat_from_euler(a[3], a[4], a[5]);
+  const V3 tp = mk(a[0] - state[(size_t)PIH_F_OFFSET * n + env], a[1] - state[(size_t)(PIH_F_OFFSET + 1) * n + env], a[2] - state[(size_t)(PIH_F_OFFSET + 2) * n + env]);
+  ikq_solve(qd, sl, P, tp, tq, q0, q1);
+  if (j0 < fly::NJ) state[(size_t)(PIH_F_TARGET + j0) * n + env] = q0;
+  if (j1 < fly::NJ) state[(size_t)(PIH_F_TARGET + j1) * n + env] = q1;
+}
+
 __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
                                                              float* __restrict__ obs, float* __restrict__ reward,
                                                              unsigned char* __restrict__ done, float* __restrict__ dbg, int n) {
@@ -241,7 +257,7 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
   }
   float o[PIH_FLY_OBS_DIM], r; unsigned char d;
   fly::LaneMem mem; mem.p = lanemem + threadIdx.x; mem.stride = 64;
-  fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
+  fly::step_env<true>(S, P, P.env0 + env, a, o, &r, &d, mem, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
 #pragma unroll
   for (int w = 0; w < fly::SW; w++) state[(size_t)w * n + env] = S[w];
   if (obs) {
@@ -506,7 +522,8 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
     t = &h->ev[h->ev_used++];
     HIPCHK(h, hipEventRecord(t->a, s));
   }
-  if (h->fly) {   // one launch: controller + physics, one env per lane
+  if (h->fly) {   // controller (one env per quad of lanes), then physics (one env per lane)
+    hipLaunchKernelGGL(pih_fly_pre_kernel, dim3((h->cfg.n_envs + 63) / 64), dim3(256), 0, s, h->P, h->state, actions, h->cfg.n_envs);
     if (t) HIPCHK(h, hipEventRecord(t->b, s));
     hipLaunchKernelGGL(pih_fly_step_kernel, dim3((h->cfg.n_envs + 63) / 64), dim3(64), (size_t)fly::LANE_WORDS * 64 * sizeof(float), s, h->P, h->state, actions, obs, reward, done,
                        h->dbg, h->cfg.n_envs);
@@ -588,7 +605,7 @@ int pih_set_state(pih_handle* h, int field, const void* in_dev, void* stream) {
 int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream) {
   if (!h || n <= 0 || !q0_dev || !tpos_dev || !tquat_dev || !qout_dev) return -2;
   PIH_ENTER(h);
-  hipLaunchKernelGGL(pih_ik_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, n, q0_dev, tpos_dev, tquat_dev, qout_dev);
+  hipLaunchKernelGGL(pih_ik_kernel, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, h->P, n, q0_dev, tpos_dev, tquat_dev, qout_dev);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -596,7 +613,7 @@ int pih_ik(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, con
 int pih_ik_ur5(pih_handle* h, int n, const float* q0_dev, const float* tpos_dev, const float* tquat_dev, float* qout_dev, void* stream) {
   if (!h || n <= 0 || !q0_dev || !tpos_dev || !tquat_dev || !qout_dev) return -2;
   PIH_ENTER(h);
-  hipLaunchKernelGGL(pih_ik_ur5_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, n, q0_dev, tpos_dev, tquat_dev, qout_dev);
+  hipLaunchKernelGGL(pih_ik_ur5_kernel, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, h->P, n, q0_dev, tpos_dev, tquat_dev, qout_dev);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

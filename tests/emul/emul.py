@@ -55,6 +55,8 @@ def lib(prec):
         L.emul_set_dv.argtypes = [C.c_void_p, C.c_double]
         L.emul_ik.argtypes = [C.POINTER(PihConfig), dp, dp, dp, dp]
         L.emul_ik_ur5.argtypes = [C.POINTER(PihConfig), dp, dp, dp, dp]
+        L.emul_ikq.argtypes = [C.POINTER(PihConfig), dp, dp, dp, dp, dp]
+        L.emul_ikq_ur5.argtypes = [C.POINTER(PihConfig), dp, dp, dp, dp, dp]
         L.emul_fly_create.restype = C.c_void_p
         L.emul_fly_create.argtypes = [C.POINTER(PihConfig), dp, C.c_double]
         L.emul_fly_destroy.argtypes = [C.c_void_p]
@@ -117,6 +119,15 @@ def ik_ur5(q0, tpos, tquat, prec="f64", cfg=None):
     q0 = np.ascontiguousarray(q0, dtype=np.float64); tp = np.ascontiguousarray(tpos, dtype=np.float64)
     tq = np.ascontiguousarray(tquat, dtype=np.float64); out = np.zeros(6)
     lib(prec).emul_ik_ur5(C.byref(cfg), _dp(q0), _dp(tp), _dp(tq), _dp(out)); return out
+
+
+def ikq(q0, tpos, tquat, prec="f64", cfg=None, ur5=False):
+    """the quad-per-env IK of pih_ikq.h, its four lanes as four host threads in lockstep -> (q*, ee pose of the START pose as seen by each
+    of the four lanes [4, 12] = xyz + row-major rotation)"""
+    cfg = cfg or default_config()
+    q0 = np.ascontiguousarray(q0, dtype=np.float64); tp = np.ascontiguousarray(tpos, dtype=np.float64)
+    tq = np.ascontiguousarray(tquat, dtype=np.float64); out = np.zeros(6 if ur5 else 9); ee = np.zeros((4, 12))
+    (lib(prec).emul_ikq_ur5 if ur5 else lib(prec).emul_ikq)(C.byref(cfg), _dp(q0), _dp(tp), _dp(tq), _dp(out), _dp(ee)); return out, ee
 
 
 class EmulFly:

@@ -6,6 +6,9 @@
 #include "pih_wave_host.h"                                  // host wave layer (+ the product's pih_common.h)
 #include "../../peg_in_hole_gym_amd/csrc/pih_step.h"        // the product's step, instantiated with the host wave layer
 #include "../../peg_in_hole_gym_amd/csrc/pih_fly.h"
+#include "../../peg_in_hole_gym_amd/csrc/pih_ikq.h"         // one env per quad of lanes: here four host threads in lockstep (QuadHost)
+#include <atomic>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -25,6 +28,44 @@ static Params make_params(const pih_config* c) {
   P.dv = (real)c->dv; P.iters = c->solver_iters; P.ikiters = c->ik_iters; P.mode = c->mode; P.maxsteps = c->max_episode_steps;
   P.autoreset = c->auto_reset; P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball; P.noprio = 1; P.checkstride = c->exit_check_stride < 1 ? 1 : c->exit_check_stride; P.object = c->object_id;
   return P;
+}
+
+// ---- quad-per-env IK (pih_ikq.h): the four lanes of a quad are four host threads; every cross-lane primitive is
+// publish -> barrier -> read -> barrier, i.e. the lockstep semantics of a DPP quad_perm read
+struct QuadBarrier {
+  std::atomic<int> count{0}, gen{0};
+  void wait() { const int g = gen.load(); if (count.fetch_add(1) == 3) { count.store(0); gen.fetch_add(1); } else while (gen.load() == g) std::this_thread::yield(); }
+};
+struct QuadShared { real slot[4]; QuadBarrier bar; };
+struct QuadHost {
+  int l; QuadShared* sh;
+  int lane4() const { return l; }
+  real from(real x, int src) const { sh->slot[l] = x; sh->bar.wait(); const real r = sh->slot[src]; sh->bar.wait(); return r; }
+  template <int K> real bcast(real x) const { return from(x, K); }
+  real shr1(real x) const { return from(x, l >= 1 ? l - 1 : l); }
+  real shr2(real x) const { return from(x, l >= 2 ? l - 2 : l); }
+  real xor1(real x) const { return from(x, l ^ 1); }
+  real xor2(real x) const { return from(x, l ^ 2); }
+};
+template <class C> static void ikq_host(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout, double* ee_out) {
+  const Params P = make_params(c);
+  QuadShared sh;
+  Q4 tq; tq.x = (real)tquat[0]; tq.y = (real)tquat[1]; tq.z = (real)tquat[2]; tq.w = (real)tquat[3];
+  const V3 tp = mk((real)tpos[0], (real)tpos[1], (real)tpos[2]);
+  real res[8]; real eep[4][12];
+  std::thread th[4];
+  for (int l = 0; l < 4; l++) th[l] = std::thread([&, l]() {
+    QuadHost qd; qd.l = l; qd.sh = &sh;
+    const QuadSlots s = ikq_slots<C>(qd);
+    real a = 2 * l < C::N ? (real)q0[2 * l] : (real)0, b = 2 * l + 1 < C::N ? (real)q0[2 * l + 1] : (real)0;
+    V3 p; M3 Re; ikq_ee(qd, s, a, b, p, Re);                       // forward kinematics of the start pose (checked by the caller)
+    eep[l][0] = p.x; eep[l][1] = p.y; eep[l][2] = p.z; for (int i = 0; i < 9; i++) eep[l][3 + i] = Re.m[i];
+    ikq_solve(qd, s, P, tp, tq, a, b);
+    res[2 * l] = a; res[2 * l + 1] = b;
+  });
+  for (int l = 0; l < 4; l++) th[l].join();
+  for (int i = 0; i < C::N; i++) qout[i] = (double)res[i];
+  if (ee_out) for (int l = 0; l < 4; l++) for (int i = 0; i < 12; i++) ee_out[12 * l + i] = (double)eep[l][i];
 }
 
 extern "C" {
@@ -84,6 +125,13 @@ void emul_ik_ur5(const pih_config* c, const double* q0, const double* tpos, cons
   Q4 tq; tq.x = (real)tquat[0]; tq.y = (real)tquat[1]; tq.z = (real)tquat[2]; tq.w = (real)tquat[3];
   ik_chain<Ur5Chain>(w, ikT, P, q, mk((real)tpos[0], (real)tpos[1], (real)tpos[2]), tq, qo);
   for (int i = 0; i < 6; i++) qout[i] = (double)qo[i];
+}
+
+void emul_ikq(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout, double* ee_out /* [4][12] or NULL */) {
+  ikq_host<PandaChain>(c, q0, tpos, tquat, qout, ee_out); qout[7] = q0[7]; qout[8] = q0[8];
+}
+void emul_ikq_ur5(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout, double* ee_out) {
+  ikq_host<Ur5Chain>(c, q0, tpos, tquat, qout, ee_out);
 }
 
 // ---- 'random-fly' task (pih_fly.h): the same per-lane scalar code the GPU runs, one env after the other

@@ -25,23 +25,28 @@ def sims(n, **kw):
 
 # 1. random actions from reset, short episodes with auto-reset (reset path inside the step), library defaults
 n = 4
-o, e = sims(n, seed=3, auto_reset=1, max_episode_steps=60)
-for t in range(steps):
+o, e = sims(n, seed=3, auto_reset=1, max_episode_steps=150)
+for t in range(2 * steps):
     a = rng.uniform(-1, 1, (n, 4)); o.step(a); e.step(a)
 assert np.isfinite(o.get_state()).all() and np.isfinite(e.get_state()[:, :128]).all()
-print("action mode: %d steps x %d envs, contacts max %d / %d" % (steps, n, o.ncontacts().max(), int(e.get_state()[:, 106].max())))
+print("action mode: %d steps x %d envs, contacts max %d / %d" % (2 * steps, n, o.ncontacts().max(), int(e.get_state()[:, 106].max())))
 
-# 2. scripted gripper pressed onto a pipe coiled flat on the table: 25..48 contacts (two rows per lane, DOF space, global-scratch spill)
+# 2. pipes coiled flat on the table under a hovering arm: 25 table + up to ~17 self contacts (two rows per lane, DOF space beyond 32
+#    contacts, global-scratch spill beyond 20), then the scripted gripper coming down on the coil (weld / finger rows)
 n = 2
-o, e = sims(n, seed=2, mode=1, dv=0.05)
-s = coil_pipe_flat(o.get_state()); o.set_state(s)
-se = e.get_state(); se[:, :98] = s[:, :98]; se[:, 128] = 0; e.set_state(se)
+s8 = coil_pipe_flat(O.Oracle(8, lib_path=ASAN_ORACLE, seed=2).get_state())[6:8]
+p0, _ = O.fk_arm(REST, 9)
 cmax = 0
-for t in range(steps + 100):
-    o.step(np.zeros((n, 4))); e.step(np.zeros((n, 4)))
-    cmax = max(cmax, int(o.ncontacts().max()), int(e.get_state()[:, 106].max()))
+for kw, act, k in ((dict(seed=2), np.tile([p0[0], p0[1], p0[2], 0.0], (n, 1)), steps), (dict(seed=2, mode=1, dv=0.05), np.zeros((n, 4)), steps + 100)):
+    o, e = sims(n, **kw)
+    o.set_state(s8.copy())
+    se = e.get_state(); se[:, :98] = s8[:, :98]; se[:, 128] = 0; e.set_state(se)
+    for t in range(k):
+        o.step(act); e.step(act)
+        cmax = max(cmax, int(o.ncontacts().max()), int(e.get_state()[:, 106].max()))
+    assert np.isfinite(o.get_state()).all() and np.isfinite(e.get_state()[:, :128]).all()
 assert cmax > 32, cmax
-print("scripted coil: %d steps, up to %d contacts" % (steps + 100, cmax))
+print("coiled pipe (hover + scripted gripper): up to %d contacts" % cmax)
 
 # 3. random-fly (UR5 + free-flying object), both objects
 for obj in (0, 1):

@@ -35,7 +35,9 @@ def test_first_exceedance_of_1000_free_running_random_action_steps(oracle_mod, N
     g = P.GpuProduct(N, seed=5)
     c = g.cfg
     assert abs(c.residual_threshold - 1e-7) < 1e-12 and abs(c.warmstart - 0.85) < 1e-6 and c.exit_check_stride == 16 and c.solver_iters == 50 and c.auto_reset == 0
-    ys = ("Y3", "Y4") if N > 1024 else ("Y1", "Y2", "Y3", "Y4")      # (4096 envs: the two yardsticks the assertions use -- each is 4.1 M fp64 env-steps on the host)
+    # every yardstick is N x 1000 fp64 env-steps on the host (70 s at N = 4096 on a GPU box's 16 cores): all four at N = 1, the two the
+    # assertions use at 1 024, Y4 alone at 4 096 (profiles/r04_first_exceedance.json holds Y3 at 4 096 as well, from tools/first_exceedance.py)
+    ys = ("Y4",) if N > 1024 else (("Y3", "Y4") if N > 1 else ("Y1", "Y2", "Y3", "Y4"))
     r = P.first_exceedance_run(oracle_mod, g, N, 1000, seed=5, yardsticks=ys, progress=(lambda s: print("   N=%d %s" % (N, s), flush=True)) if N >= 1024 else None)
     first = r.pop("first")
     r["product_kind"] = "HIP (libpih_hip.so through the C ABI), library defaults; oracle fp64 at Bullet's exit cadence"
@@ -45,15 +47,20 @@ def test_first_exceedance_of_1000_free_running_random_action_steps(oracle_mod, N
     for m in ("pose", "force", "obs"):
         print("N=%d first exceedance [%s]: " % (N, m) + " | ".join("%s q05/q10/q25/q50 %d/%d/%d/%d never %.1f %%" % (
             k, v["q05"], v["q10"], v["q25"], v["q50"], 100 * v["never_share"]) for k, v in r[m].items()))
-    print("N=%d: product within 1e-3 m on %.2f %% of all env-steps (Y3 %.2f %%, Y4 %.2f %%); before the first exceedance: tip err p50 %.2e p99 %.2e" % (
-        N, 100 * r["env_steps_within_tolerance_share"]["product"], 100 * r["env_steps_within_tolerance_share"]["Y3"], 100 * r["env_steps_within_tolerance_share"]["Y4"],
-        *r["product_tip_err_p50_p99_before_first_exceedance"]))
+    print("N=%d: within 1e-3 m on this share of all env-steps: %s; before the first exceedance: tip err p50 %.2e p99 %.2e" % (
+        N, {k: round(v, 4) for k, v in r["env_steps_within_tolerance_share"].items()}, *r["product_tip_err_p50_p99_before_first_exceedance"]))
     assert r["product_max_tip_err_before_first_exceedance"] <= 1e-3 and r["product_max_obs_err_before_first_exceedance"] <= 1e-3
     if N == 1:
         return          # one env: the step numbers are the report (no quantiles to compare)
     for m in ("pose", "force", "obs"):
-        p, y3, y4 = r[m]["product"], r[m]["Y3"], r[m]["Y4"]
+        p, y3, y4 = r[m]["product"], r[m].get("Y3"), r[m]["Y4"]
         for q in ("q05", "q10", "q25", "q50", "q75"):
-            assert p[q] >= 0.8 * y4[q] - 2, "%s %s: product %d vs Y4 %d" % (m, q, p[q], y4[q])
-            assert p[q] >= 0.5 * y3[q] - 2, "%s %s: product %d vs Y3 %d" % (m, q, p[q], y3[q])
+            # (a quantile that sits in the yardstick's "never within 1 000 steps" mass is compared through never_share below)
+            if y4[q] < r["steps"]:
+                assert p[q] >= 0.8 * y4[q] - 2, "%s %s: product %d vs Y4 %d" % (m, q, p[q], y4[q])
+            if y3 is not None and y3[q] < r["steps"]:
+                assert p[q] >= 0.5 * y3[q] - 2, "%s %s: product %d vs Y3 %d" % (m, q, p[q], y3[q])
         assert p["never_share"] >= y4["never_share"] - 0.05, (m, p["never_share"], y4["never_share"])
+        if y3 is not None:
+            print("N=%d [%s] product / Y3 quantile ratios: %s ; never-exceeding share product %.3f, Y3 %.3f, Y4 %.3f" % (
+                N, m, {q: round(p[q] / y3[q], 2) for q in ("q05", "q10", "q25", "q50") if y3[q] < r["steps"]}, p["never_share"], y3["never_share"], y4["never_share"]))

@@ -275,7 +275,7 @@ def test_new_seed_needs_a_full_reset(torch_mod):
     g.reset()                                                  # consumes the pending reseed: seed 5's first scene
     assert torch.equal(g.state()[:, :98], _gpu(n, seed=5).state()[:, :98])
     g.reset(mask)                                              # masked resets are fine again afterwards
-    assert (g.state()[mask == 1][:, 92] > g.state()[mask == 0][:, 92]).all()
+    assert g.state()[mask == 1][:, 92].min() > g.state()[mask == 0][:, 92].max()
 
 
 def test_roctx_ranges_do_not_disturb_the_step(torch_mod):

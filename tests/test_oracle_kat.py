@@ -257,4 +257,4 @@ def test_new_seed_needs_a_full_reset_oracle(oracle_mod):
     o.reset()
     np.testing.assert_array_equal(o.get_state()[:, :91], oracle_mod.Oracle(6, seed=5).get_state()[:, :91])
     o.reset(m)
-    assert (o.get_state()[m == 1][:, 92] > o.get_state()[m == 0][:, 92]).all()
+    assert o.get_state()[m == 1][:, 92].min() > o.get_state()[m == 0][:, 92].max()
