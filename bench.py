@@ -81,7 +81,11 @@ def valu_issue(fly=False):
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         per_wave = d["frac_SQ_ACTIVE_INST_VALU"]; waves = d.get("waves_per_simd", 2)
-        return {"frac_valu_issue": per_wave * waves, "valu_active_per_wave": per_wave, "waves_per_simd": waves,
+        # launch_wide: VALU-active cycles summed over all waves / (1024 SIMDs x the kernel's span in engine clocks, GRBM_GUI_ACTIVE of the same
+        # dispatches) -- includes the tail of the launch, where SIMDs run one wave or none; frac_valu_issue (per resident wave x waves per
+        # SIMD) only describes a SIMD while both of its wave slots are full
+        return {"frac_valu_issue": per_wave * waves, "launch_wide": d.get("launch_wide_valu_issue"), "launch_span_cycles": d.get("launch_span_cycles"),
+                "valu_active_per_wave": per_wave, "waves_per_simd": waves,
                 "wait_any_per_wave": d.get("frac_SQ_WAIT_ANY"), "valu_insts_per_env_step": d.get("valu_insts_per_env_step"),
                 "source": "profiles/%s (%s)" % (name, d.get("tag")), "measured_on_source_sha16": d.get("source_sha16"),
                 "stale": d.get("source_sha16") != _source_sha16()}
@@ -405,7 +409,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (alg_bytes * n),
                          "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel", "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches, "event_stride": args.timing_stride,
-                         "alg_bytes_per_env_step": alg_bytes, "valu_issue": vi, "frac_valu_issue": vi["frac_valu_issue"] if vi else None, "flops": flops, "note": note},
+                         "alg_bytes_per_env_step": alg_bytes, "valu_issue": vi, "frac_valu_issue": vi["frac_valu_issue"] if vi else None, "frac_valu_issue_launch_wide": vi["launch_wide"] if vi else None, "flops": flops, "note": note},
             "sanity": {"state_finite": finite, "mean_contacts": 0.5 * (c_start + c_end), "mean_contacts_start": c_start, "mean_contacts_end": c_end,
                        "pgs_variant_share": variants,
                        ("mean_episode_step" if fly else "mean_pgs_iters"): mean_iters},

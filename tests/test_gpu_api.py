@@ -274,8 +274,10 @@ def test_new_seed_needs_a_full_reset(torch_mod):
         g.reset(mask)
     g.reset()                                                  # consumes the pending reseed: seed 5's first scene
     assert torch.equal(g.state()[:, :98], _gpu(n, seed=5).state()[:, :98])
-    g.reset(mask)                                              # masked resets are fine again afterwards
-    assert g.state()[mask == 1][:, 92].min() > g.state()[mask == 0][:, 92].max()
+    before = g.state()[:, 92].clone()
+    g.reset(mask)                                              # masked resets are fine again afterwards: the masked envs draw on, the others rest
+    after = g.state()[:, 92]
+    assert (after[mask == 1] > before[mask == 1]).all() and torch.equal(after[mask == 0], before[mask == 0])
 
 
 def test_roctx_ranges_do_not_disturb_the_step(torch_mod):

@@ -256,5 +256,7 @@ def test_new_seed_needs_a_full_reset_oracle(oracle_mod):
     np.testing.assert_array_equal(o.get_state(), s0)
     o.reset()
     np.testing.assert_array_equal(o.get_state()[:, :91], oracle_mod.Oracle(6, seed=5).get_state()[:, :91])
+    before = o.get_state()[:, 92].copy()
     o.reset(m)
-    assert o.get_state()[m == 1][:, 92].min() > o.get_state()[m == 0][:, 92].max()
+    after = o.get_state()[:, 92]
+    assert (after[m == 1] > before[m == 1]).all() and np.array_equal(after[m == 0], before[m == 0])

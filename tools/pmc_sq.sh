@@ -12,8 +12,12 @@ P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT
 P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_BANK_CONFLICT"
 # executed fp32 work (wave-instructions: x 64 lanes = lane-flops, idle and redundant wave-uniform lanes included)
 P3="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM SQ_INSTS_FLAT"
+# launch-wide issue fraction: GRBM_GUI_ACTIVE = cycles the GPU was busy with the dispatch (the kernel's span in engine clocks), measured in the
+# same pass as the VALU-active quad-cycles it is compared with (round-3 review: the per-wave figure x 2 assumed both wave slots of every
+# SIMD full for the whole launch)
+P4="GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES"
 i=0
-for C in "$P1" "$P2" "$P3"; do
+for C in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/sq_${TAG}${SUF}_$i
   timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/sq_${TAG}${SUF}_$i -- python $R/bench.py --task $TASK --steps 40 --warmup 20 --no-cpu-baseline > $R/gpurun_out/sq_${TAG}${SUF}_$i.bench.json 2> $R/gpurun_out/sq_${TAG}${SUF}_$i.err
@@ -30,10 +34,18 @@ suf, kernel = ("_fly", "pih_fly_step_kernel") if fly else ("", "pih_step_kernel"
 out = {"tag": tag, "task": task, "kernel": kernel, "units": "per launch (SQ cycle counters are quad-cycles summed over waves)", "source_sha16": source_sha16(),
        "waves_per_simd": 1 if fly else 2}
 acc = {}
+span = []          # (GRBM_GUI_ACTIVE, SQ_ACTIVE_INST_VALU) of the SAME dispatches (pass 4)
 for f in glob.glob("gpurun_out/sq_%s%s_[0-9]/**/*counter_collection.csv" % (tag, suf), recursive=True):
+    p4 = "/sq_%s%s_4/" % (tag, suf) in f
+    per = {}
     for r in csv.DictReader(open(f)):
         if kernel in r["Kernel_Name"]:
+            if p4:
+                per.setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
+                if r["Counter_Name"] != "GRBM_GUI_ACTIVE":
+                    continue
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    span += [(d["GRBM_GUI_ACTIVE"], d["SQ_ACTIVE_INST_VALU"]) for d in per.values() if "GRBM_GUI_ACTIVE" in d and "SQ_ACTIVE_INST_VALU" in d]
 for k, v in sorted(acc.items()):
     out[k] = sum(v) / len(v)
 n_envs = 4096
@@ -46,6 +58,13 @@ if w:
     for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_LDS"):
         if k in out:
             out["frac_" + k] = out[k] / w
+if span:
+    # SQ_ACTIVE_INST_VALU counts quad-cycles (x 4 = cycles) summed over all waves; the chip has 256 CUs x 4 SIMDs, each of which can have ONE
+    # VALU instruction in flight: launch-wide fraction of the VALU issue capacity = sum / (1024 SIMDs x span in cycles)
+    tail = span[len(span) // 2:]          # the later dispatches of the run (contact steady state)
+    out["n_simds"] = 1024
+    out["launch_wide_valu_issue"] = sum(4.0 * v / (1024.0 * g) for g, v in tail) / len(tail)
+    out["launch_span_cycles"] = sum(g for g, _ in tail) / len(tail)
 json.dump(out, open("gpurun_out/sq_%s%s.json" % (tag, suf), "w"), indent=1)
 print(json.dumps(out))
 PY
