@@ -257,7 +257,7 @@ def main():
     ap.add_argument("--solver-path", type=int, default=0, help="1 = DOF-space PGS for every env (A/B against the default row-space path for <= 10 contacts)")
     ap.add_argument("--timing-stride", type=int, default=4, help="HIP events bracket every k-th step launch of the timed region (3 event records per step cost ~30 us of queue drain on a 430 us step; k = 1: every launch)")
     ap.add_argument("--exit-check-stride", type=int, default=0, help="cadence of the PGS early-exit test: 0 = library default (16), 1 = Bullet's (every iteration)")
-    ap.add_argument("--schedule", type=int, default=1, help="dispatch order: 1 longest-job-first (default), 0 env order, 2 partner-aware (experimental); +4: no wave priority for heavy envs")
+    ap.add_argument("--schedule", type=int, default=1, help="dispatch order: 1 longest-job-first (default), 0 env order, 2 partner-aware (experimental); +4: no wave priority for heavy envs; +8: controller / IK one env per lane (rounds 1-3) instead of per quad")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--force-collective", action="store_true", help="initialise the process group and run the per-step all-gather / barrier / all-reduce even at world size 1 (exercises the RCCL path of configs[3] on a 1-GPU box)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (1-GPU box, gloo backend)")
@@ -311,7 +311,7 @@ def main():
     if use_gpu:
         from peg_in_hole_gym_amd.vec_env import PihVecEnv
         if fly:
-            env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, seed=args.seed, task_id=1, dt=1.0 / 120.0, max_episode_steps=480, contact_margin=0.02)
+            env = PihVecEnv(n, device=dev, env_index0=rank * n, auto_reset=1, seed=args.seed, task_id=1, dt=1.0 / 120.0, max_episode_steps=480, contact_margin=0.02, schedule=args.schedule)
         else:
             mode_kw = dict(mode=1, dv=0.05) if args.mode == "scripted" else {}
             if args.exit_check_stride > 0:

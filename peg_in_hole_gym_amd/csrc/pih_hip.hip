@@ -29,31 +29,33 @@ constexpr int PRE_THREADS = 256;
 // heaviest env of the launch with the lightest one in the same slot -- the launch then ends a whole light env after the heaviest one.
 // Here the first wave of m blocks is the m - sched_k heaviest envs plus the sched_k LIGHTEST ones; the slots of those finish early, take
 // a second and a third light env, and the slots of the heaviest envs are never handed a second one.  sched_heads = m - sched_k.
+__device__ __forceinline__ void pre_sort_block(float* __restrict__ state, int* __restrict__ order, int n, int sched_heads, int sched_k) {
+  const int t = threadIdx.x;
+  if (!order) return;
+  __shared__ int hist[64], base[64];
+  if (t < 64) hist[t] = 0;
+  __syncthreads();
+  for (int e = t; e < n; e += PRE_THREADS) {
+    int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
+    k = k < 0 ? 0 : (k > 63 ? 63 : k);
+    atomicAdd(&hist[63 - k], 1);          // bin 0 = most contacts
+  }
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int b = 0; b < 64; b++) { base[b] = acc; acc += hist[b]; } }
+  __syncthreads();
+  for (int e = t; e < n; e += PRE_THREADS) {
+    int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
+    k = k < 0 ? 0 : (k > 63 ? 63 : k);
+    int r = atomicAdd(&base[63 - k], 1);
+    if (sched_k > 0 && n > sched_heads + sched_k && r >= sched_heads) r = r >= n - sched_k ? sched_heads + (n - 1 - r) : r + sched_k;
+    order[r] = e;
+  }
+}
+
 __global__ void __launch_bounds__(PRE_THREADS) pih_pre_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
                                                                int* __restrict__ order, int n, int sched_heads, int sched_k) {
   const int t = threadIdx.x;
-  if (blockIdx.x == 0) {
-    if (!order) return;
-    __shared__ int hist[64], base[64];
-    if (t < 64) hist[t] = 0;
-    __syncthreads();
-    for (int e = t; e < n; e += PRE_THREADS) {
-      int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
-      k = k < 0 ? 0 : (k > 63 ? 63 : k);
-      atomicAdd(&hist[63 - k], 1);          // bin 0 = most contacts
-    }
-    __syncthreads();
-    if (t == 0) { int acc = 0; for (int b = 0; b < 64; b++) { base[b] = acc; acc += hist[b]; } }
-    __syncthreads();
-    for (int e = t; e < n; e += PRE_THREADS) {
-      int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT];
-      k = k < 0 ? 0 : (k > 63 ? 63 : k);
-      int r = atomicAdd(&base[63 - k], 1);
-      if (sched_k > 0 && n > sched_heads + sched_k && r >= sched_heads) r = r >= n - sched_k ? sched_heads + (n - 1 - r) : r + sched_k;
-      order[r] = e;
-    }
-    return;
-  }
+  if (blockIdx.x == 0) { pre_sort_block(state, order, n, sched_heads, sched_k); return; }
   // controller: one env per QUAD of lanes (pih_ikq.h), 64 envs per block = 4 wavefronts of 16 envs
   const int env = (blockIdx.x - 1) * 64 + (t >> 2);
   if (env >= n) return;                                   // (uniform per quad: DPP never reads a lane that has left)
@@ -63,6 +65,22 @@ __global__ void __launch_bounds__(PRE_THREADS) pih_pre_kernel(Params P, float* _
   if (actions) { a[0] = actions[env * 4]; a[1] = actions[env * 4 + 1]; a[2] = actions[env * 4 + 2]; a[3] = actions[env * 4 + 3]; }
   QuadDpp qd; qd.l = t & 3;
   controller_targets_quad(qd, S, P, a);
+}
+
+// The round 1-3 controller launch, kept as a MEASUREMENT SWITCH (pih_config.schedule bit 3): one env per LANE, 64 envs per block on the
+// block's first wavefront (controller_targets: ik_chain, ~1 000 dependent instructions per IK iteration).  A/B partner of pih_pre_kernel.
+__global__ void __launch_bounds__(PRE_THREADS) pih_pre_lane_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
+                                                                    int* __restrict__ order, int n, int sched_heads, int sched_k) {
+  const int t = threadIdx.x;
+  if (blockIdx.x == 0) { pre_sort_block(state, order, n, sched_heads, sched_k); return; }
+  if (t >= 64) return;
+  const int env = (blockIdx.x - 1) * 64 + t;
+  if (env >= n) return;
+  float* S = state + (size_t)env * PIH_STATE_WORDS;
+  if (!P.autoreset && S[PIH_S_DONE] != 0) return;
+  float a[4] = {0, 0, 0, 0};
+  if (actions) { a[0] = actions[env * 4]; a[1] = actions[env * 4 + 1]; a[2] = actions[env * 4 + 2]; a[3] = actions[env * 4 + 3]; }
+  controller_targets(S, P, a);
 }
 
 __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __restrict__ state,
@@ -241,6 +259,7 @@ __global__ void __launch_bounds__(256) pih_fly_pre_kernel(Params P, float* __res
   if (j1 < fly::NJ) state[(size_t)(PIH_F_TARGET + j1) * n + env] = q1;
 }
 
+template <bool EXTERNAL_IK>
 __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
                                                              float* __restrict__ obs, float* __restrict__ reward,
                                                              unsigned char* __restrict__ done, float* __restrict__ dbg, int n) {
@@ -257,7 +276,7 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
   }
   float o[PIH_FLY_OBS_DIM], r; unsigned char d;
   fly::LaneMem mem; mem.p = lanemem + threadIdx.x; mem.stride = 64;
-  fly::step_env<true>(S, P, P.env0 + env, a, o, &r, &d, mem, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
+  fly::step_env<EXTERNAL_IK>(S, P, P.env0 + env, a, o, &r, &d, mem, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
 #pragma unroll
   for (int w = 0; w < fly::SW; w++) state[(size_t)w * n + env] = S[w];
   if (obs) {
@@ -440,7 +459,8 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
   if (h->fly) {
     // (dynamic LDS beyond the default 64 KB limit: the per-lane contact rows and candidate staging of 64 envs are LANE_WORDS * 64 words)
     static_assert((size_t)fly::LANE_WORDS * 64 * sizeof(float) <= 160 * 1024, "the random-fly kernel's per-wave LDS exceeds a CU's 160 KB");
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
     const int nb64 = (cfg->n_envs + 63) / 64;
     hipLaunchKernelGGL(pih_fly_init_offsets_kernel, dim3(nb64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
     hipLaunchKernelGGL(pih_fly_reset_kernel, dim3(nb64), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0, 0, cfg->n_envs);
@@ -522,15 +542,19 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
     t = &h->ev[h->ev_used++];
     HIPCHK(h, hipEventRecord(t->a, s));
   }
+  const bool lane_ctrl = (h->cfg.schedule & 8) != 0;      // measurement switch: the round 1-3 controller, one env per lane
   if (h->fly) {   // controller (one env per quad of lanes), then physics (one env per lane)
-    hipLaunchKernelGGL(pih_fly_pre_kernel, dim3((h->cfg.n_envs + 63) / 64), dim3(256), 0, s, h->P, h->state, actions, h->cfg.n_envs);
+    const dim3 grid((h->cfg.n_envs + 63) / 64); const size_t lds = (size_t)fly::LANE_WORDS * 64 * sizeof(float);
+    if (!lane_ctrl) hipLaunchKernelGGL(pih_fly_pre_kernel, grid, dim3(256), 0, s, h->P, h->state, actions, h->cfg.n_envs);
     if (t) HIPCHK(h, hipEventRecord(t->b, s));
-    hipLaunchKernelGGL(pih_fly_step_kernel, dim3((h->cfg.n_envs + 63) / 64), dim3(64), (size_t)fly::LANE_WORDS * 64 * sizeof(float), s, h->P, h->state, actions, obs, reward, done,
-                       h->dbg, h->cfg.n_envs);
+    if (lane_ctrl) hipLaunchKernelGGL(pih_fly_step_kernel<false>, grid, dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs);
+    else hipLaunchKernelGGL(pih_fly_step_kernel<true>, grid, dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs);
     if (t) HIPCHK(h, hipEventRecord(t->c, s));
     HIPCHK(h, hipGetLastError());
     return 0;
   }
+  if (lane_ctrl) hipLaunchKernelGGL(pih_pre_lane_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs, h->sched_heads, h->sched_k);
+  else
   hipLaunchKernelGGL(pih_pre_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs, h->sched_heads, h->sched_k);
   if (t) HIPCHK(h, hipEventRecord(t->b, s));
   hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, obs, reward, done, h->dbg, h->ovf, h->order);
