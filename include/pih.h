@@ -100,7 +100,8 @@ typedef struct pih_config {
   int32_t schedule;           /* 1 (default): longest-job-first dispatch order from the previous step's contact counts; 0: block i = env i;
                                  2: longest-job-first with the lightest envs as SIMD partners of the heaviest (experimental);
                                  +4: do not raise the issue priority of the wavefronts of contact-heavy envs (measurement switch);
-                                 +8: controller / IK with one env per LANE as in rounds 1-3 instead of one env per quad of lanes (measurement switch) */
+                                 +8 / +16: the two-launch step of rounds 1-3 (controller launch, then physics launch) instead of the fused launch,
+                                 with the controller / IK one env per LANE (+8) or one env per quad of lanes (+16) (measurement switches) */
   int32_t enable_arm_collision; /* arm collision spheres (pih_model.h PIH_ARM_SPH_*): bit 0 vs the table plane, bit 1 vs the pipe (hand /
                                    flange / wrist spheres against the pipe's sample spheres); default 3 */
   int32_t task_id;            /* PIH_TASK_*: which task of TASK_LIST (envs/base_env.py:9-11) the handle simulates */

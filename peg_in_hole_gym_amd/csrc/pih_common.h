@@ -407,12 +407,24 @@ PIH_HD void tip_pose_serial(const real* S, real* out) {
 // only (S[TARGET..], and in scripted mode the state-machine words), so on the GPU it runs one env per LANE in
 // pih_pre_kernel before the step kernel; the IK is 20 strictly sequential 7x7 solves, which as wave-uniform code inside the
 // one-wave-per-env step kernel cost 13 % of the step at 1/64 lane utilisation.
-PIH_HD void controller_targets(real* S, const Params& P, const real* action) {
+// What the controller changes in an env's state record (the 13 words it owns): computed by controller_compute from a READ-ONLY view of
+// the record, written by controller_apply -- into the record itself (two-launch path) or, in the fused launch, first into the env's
+// 16-word slot of the controller mailbox (pih_step_kernel's controller role) and from there into the env wave's LDS copy.
+struct CtrlOut { real target[9]; real fsm, fsmt, grasp_angle, attach_qz; };
+constexpr int CTRL_WORDS = 16;                               // mailbox record: 9 targets, fsm, fsmt, grasp_angle, attach_qz, 3 spare
+PIH_HD void controller_apply(real* S, const CtrlOut& o) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) S[PIH_S_TARGET + i] = o.target[i];
+  S[PIH_S_FSM] = o.fsm; S[PIH_S_FSMT] = o.fsmt; S[PIH_S_GRASP_ANGLE] = o.grasp_angle; S[PIH_S_ATTACH_QZ] = o.attach_qz;
+}
+PIH_HD CtrlOut controller_compute(const real* S, const Params& P, const real* action) {
   Serial sw;
   real ikT[7][12];
   real q[9];
+  CtrlOut o;
 #pragma unroll
-  for (int i = 0; i < 9; i++) q[i] = S[PIH_S_QARM + i];
+  for (int i = 0; i < 9; i++) { q[i] = S[PIH_S_QARM + i]; o.target[i] = S[PIH_S_TARGET + i]; }
+  o.fsm = S[PIH_S_FSM]; o.fsmt = S[PIH_S_FSMT]; o.grasp_angle = S[PIH_S_GRASP_ANGLE]; o.attach_qz = S[PIH_S_ATTACH_QZ];
   V3 eep; M3 eeR; chain_ee<PandaChain>(q, eep, eeR);
   if (P.mode == 0) {
     // panda_execute, envs/utils.py:60-68
@@ -422,22 +434,22 @@ PIH_HD void controller_targets(real* S, const Params& P, const real* action) {
     real qs[7];
     ik_chain<PandaChain>(sw, ikT, P, q, tp, tq, qs);
 #pragma unroll
-    for (int i = 0; i < 7; i++) S[PIH_S_TARGET + i] = qs[i];
-    S[PIH_S_TARGET + 7] = action[3]; S[PIH_S_TARGET + 8] = action[3];
+    for (int i = 0; i < 7; i++) o.target[i] = qs[i];
+    o.target[7] = action[3]; o.target[8] = action[3];
   } else {
     // random_grasp loop body, envs/peg_in_hole.py:53-112 (update_state :206-212, grasp_process :122-204)
     int st = (int)S[PIH_S_FSM];
     int nstep = (int)(S[PIH_S_FSMT] * (real)240 + (real)0.5) + 1;      // S[FSMT] holds the state clock in seconds, as the reference does
     const int st_prev = st;
     if (nstep >= FSM_STEPS[st]) { st += 1; nstep = 0; if (st >= 10) st = 0; }
-    S[PIH_S_FSM] = (real)st; S[PIH_S_FSMT] = (real)nstep * (real)(1.0 / 240.0);
+    o.fsm = (real)st; o.fsmt = (real)nstep * (real)(1.0 / 240.0);
     real tip[7]; tip_pose_serial(S, tip);
     Q4 tornq; tornq.x = tip[3]; tornq.y = tip[4]; tornq.z = tip[5]; tornq.w = tip[6];
     V3 rv = mul(q_to_m(tornq), mk(0, S[PIH_S_RANDY], 0));
     V3 tpos = mk(tip[0], tip[1], tip[2]) + rv;
     V3 tp = vel_constraint(eep, tpos, P.dv);
-    if (st == 2 && st_prev != 2) S[PIH_S_GRASP_ANGLE] = (real)atan2(rv.y, rv.x);   // label angle, envs/peg_in_hole.py:72
-    if (st == 4 && st_prev != 4) S[PIH_S_ATTACH_QZ] = tip[5];                       // targetOrn[2] of envs/peg_in_hole.py:101 (z COMPONENT of the link quaternion)
+    if (st == 2 && st_prev != 2) o.grasp_angle = (real)atan2(rv.y, rv.x);   // label angle, envs/peg_in_hole.py:72
+    if (st == 4 && st_prev != 4) o.attach_qz = tip[5];                       // targetOrn[2] of envs/peg_in_hole.py:101 (z COMPONENT of the link quaternion)
     real yaw = yaw_from_quat(tornq);
     V3 hole = ld3(HOLE_POS);
     Q4 tq; tq.x = 0; tq.y = 0; tq.z = 0; tq.w = 1;
@@ -452,13 +464,15 @@ PIH_HD void controller_targets(real* S, const Params& P, const real* action) {
       real qs[7];
       ik_chain<PandaChain>(sw, ikT, P, q, tp, tq, qs);
 #pragma unroll
-      for (int i = 0; i < 7; i++) S[PIH_S_TARGET + i] = qs[i];
+      for (int i = 0; i < 7; i++) o.target[i] = qs[i];
     }
     const bool closed = st >= 3 && st < 7;
     const real ft = closed ? (real)0.006 : (real)0.02;
-    S[PIH_S_TARGET + 7] = ft; S[PIH_S_TARGET + 8] = ft;
+    o.target[7] = ft; o.target[8] = ft;
   }
+  return o;
 }
+PIH_HD void controller_targets(real* S, const Params& P, const real* action) { const CtrlOut o = controller_compute(S, P, action); controller_apply(S, o); }
 
 // Controller, part 2 (inside the step kernel): motor rows from the targets in the state record.
 // btMultiBodyJointMotor desired velocity = kp (q* - q)/dt (+ qd - kd qd, kd = 1); default load-time velocity motor

@@ -83,12 +83,65 @@ __global__ void __launch_bounds__(PRE_THREADS) pih_pre_lane_kernel(Params P, flo
   controller_targets(S, P, a);
 }
 
-__global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __restrict__ state,
+// ---- the fused launch (round 4): ONE launch per step.
+// Rounds 1-3 ran two launches per step: pih_pre_kernel (dispatch-order sort + controller, 33 us of which ~10 us are the gap between two
+// dependent launches, on 64 of the chip's 1 024 SIMDs) and then pih_step_kernel (313 us at 4 096 envs).  Here the step kernel's grid is
+// G = ceil(n / 64) CONTROLLER wavefronts (blocks 0 .. G - 1, dispatched first) followed by the n env wavefronts:
+//   * a controller wavefront runs controller_compute for 64 envs, one per lane, from the envs' state records as the previous launch left
+//     them, writes each env's 13 controller words into its mailbox record and publishes the group with a release store of the launch's
+//     epoch; it never waits for anything;
+//   * an env wavefront does forward kinematics, collision detection and the articulated-body sweep (~22 us), then waits -- bounded,
+//     s_sleep between polls -- for its group's flag and takes the controller words from the mailbox (Wave::await_controller); the
+//     controller needs ~25 us, so the first round of env waves waits a few us and the second round not at all;
+//   * the dispatch order for the NEXT launch is built by the env wavefronts themselves: at its end an env takes a slot in the bin of its
+//     contact count (atomicAdd; bin 0 = most contacts) of the "next" bin buffer; at its start block b finds "its" env by a prefix sum
+//     over the 64 bin counts of the "current" buffer.  Three buffers rotate (current / next / being zeroed), so no launch ever reads a
+//     count another wave of the same launch is still changing.  Results do not depend on the order (tests/test_gpu_api.py).
+struct FusedArgs {
+  int G, n, epoch;               // G = 0: two-launch path (no controller role, no mailbox)
+  const int* bcur; int* bnext; int* bzero;   // bin buffers: [64 counts][64 x n slots]; nullptr: block b = env b (schedule 0) or `order`
+  float* mail; int* flags; int* err;
+};
+__device__ __forceinline__ int fused_lookup_env(const int* __restrict__ bcur, int b, int n, int lane) {
+  int p = bcur[lane];
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(p, d); if (lane >= d) p += t; }
+  const unsigned long long m = __ballot(p > b);
+  if (m == 0) return b;                                      // (inconsistent bins cannot happen; stay in range if they do)
+  const int k = __ffsll((long long)m) - 1;
+  const int base = k > 0 ? __shfl(p, k - 1) : 0;
+  const int e = bcur[64 + (size_t)k * n + (b - base)];
+  return e >= 0 && e < n ? e : b;
+}
+
+__global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
                                                       float* __restrict__ obs, float* __restrict__ reward,
                                                       unsigned char* __restrict__ done, float* __restrict__ dbg,
-                                                      float* __restrict__ ovf, const int* __restrict__ order) {
+                                                      float* __restrict__ ovf, const int* __restrict__ order, FusedArgs F) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x < F.G) {
+    // ---- controller role: 64 envs, one per lane (controller_compute: the strictly sequential IK)
+    if (blockIdx.x == 0 && F.bzero) F.bzero[lane] = 0;
+    const int env = blockIdx.x * 64 + lane;
+    if (env < F.n) {
+      const float* S = state + (size_t)env * PIH_STATE_WORDS;
+      if (P.autoreset || S[PIH_S_DONE] == 0) {               // finished envs keep their last values (envs/base_env.py:62,66): their waves do not read the mailbox
+        float a[4] = {0, 0, 0, 0};
+        if (actions) { a[0] = actions[env * 4]; a[1] = actions[env * 4 + 1]; a[2] = actions[env * 4 + 2]; a[3] = actions[env * 4 + 3]; }
+        const CtrlOut o = controller_compute(S, P, a);
+        float* m = F.mail + (size_t)env * CTRL_WORDS;
+#pragma unroll
+        for (int i = 0; i < 9; i++) m[i] = o.target[i];
+        m[9] = o.fsm; m[10] = o.fsmt; m[11] = o.grasp_angle; m[12] = o.attach_qz;
+      }
+    }
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(F.flags + blockIdx.x, F.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   __shared__ Shared sh;
-  const int env = order ? order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.x - F.G;
+  const int env = __builtin_amdgcn_readfirstlane(F.bcur ? fused_lookup_env(F.bcur, b, F.n, lane) : (order ? order[b] : b));   // (wave-uniform by construction; the scalar makes it so for the compiler)
   Wave w; w.l = lane; w.counter = 0;
   float* rec = state + (size_t)env * PIH_STATE_WORDS;
 #pragma unroll
@@ -97,12 +150,29 @@ __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __rest
   float o[5], r; unsigned char d;
   Ovf ov; ov.base = ovf + (size_t)env * OVF_WORDS;
   w.dbg = dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr; w.dbgmode = P.debug; w.prio_on = !P.noprio;
+  if (F.G > 0) { w.cflags = F.flags; w.cmail = F.mail; w.cerr = F.err; w.cepoch = F.epoch; w.cenv = env; }
   step_env(w, sh, P, ov, env, nullptr, o, &r, &d, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < PIH_STATE_WORDS / 64; i++) rec[lane + 64 * i] = sh.S[lane + 64 * i];
   if (lane < 5 && obs) obs[env * 5 + lane] = o[0] * (lane == 0) + o[1] * (lane == 1) + o[2] * (lane == 2) + o[3] * (lane == 3) + o[4] * (lane == 4);
-  if (lane == 0) { if (reward) reward[env] = r; if (done) done[env] = d; }
+  if (lane == 0) {
+    if (reward) reward[env] = r; if (done) done[env] = d;
+    if (F.bnext) {                                           // a slot in the next launch's dispatch order: bin 0 = most contacts
+      int k = (int)sh.S[PIH_S_NCONTACT]; k = k < 0 ? 0 : (k > 63 ? 63 : k);
+      const int rnk = atomicAdd(F.bnext + (63 - k), 1);
+      if (rnk < F.n) F.bnext[64 + (size_t)(63 - k) * F.n + rnk] = env;
+    }
+  }
+}
+
+// first fill of a bin buffer (pih_create): the same counting sort, from the state records
+__global__ void __launch_bounds__(256) pih_bins_init_kernel(const float* __restrict__ state, int* __restrict__ bins, int n) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    int k = (int)state[(size_t)e * PIH_STATE_WORDS + PIH_S_NCONTACT]; k = k < 0 ? 0 : (k > 63 ? 63 : k);
+    const int rnk = atomicAdd(bins + (63 - k), 1);
+    bins[64 + (size_t)(63 - k) * n + rnk] = e;
+  }
 }
 
 // hard (resetSimulation, envs/base_env.py:85-86): a NEW scene like every reset (the reference keeps drawing from the global `random`); it
@@ -356,7 +426,11 @@ struct pih_handle {
   float* state = nullptr;
   float* dbg = nullptr;
   float* ovf = nullptr;     // spill area for contacts beyond the LDS-resident CL (rarely touched)
-  int* order = nullptr;     // longest-job-first block -> env map (block 0 of pih_pre_kernel)
+  int* order = nullptr;     // longest-job-first block -> env map (block 0 of pih_pre_kernel; two-launch path)
+  // fused launch (default for the peg-in-hole task): controller mailbox + group flags + error word, three rotating bin buffers of the
+  // in-kernel dispatch order, the launch counter
+  bool fused = false;
+  float* mail = nullptr; int* flags = nullptr; int* errw = nullptr; int* bins = nullptr; size_t bin_ints = 0; int epoch = 0;
   std::string err;
   int timing = 0;           // 0 off; k >= 1: every k-th step launch is bracketed by events (pih_set_timing)
   unsigned timing_tick = 0;
@@ -441,6 +515,10 @@ int pih_destroy(pih_handle* h) {
   if (h->dbg) hipFree(h->dbg);
   if (h->ovf) hipFree(h->ovf);
   if (h->order) hipFree(h->order);
+  if (h->mail) hipFree(h->mail);
+  if (h->flags) hipFree(h->flags);
+  if (h->errw) hipFree(h->errw);
+  if (h->bins) hipFree(h->bins);
   delete h;
   return 0;
 }
@@ -471,6 +549,23 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
   HIPCHK(h, hipMalloc(&h->ovf, ((size_t)cfg->n_envs * OVF_WORDS + OVF_PAD_WORDS) * sizeof(float)));
   HIPCHK(h, hipMemset(h->ovf, 0, ((size_t)cfg->n_envs * OVF_WORDS + OVF_PAD_WORDS) * sizeof(float)));
   if (cfg->schedule & 3) HIPCHK(h, hipMalloc(&h->order, (size_t)cfg->n_envs * sizeof(int)));
+  // fused launch unless a measurement switch asks for the two-launch path (schedule + 8: controller one env per lane, + 16: one env per
+  // quad) or for the experimental partner-aware order (schedule & 3 == 2, which only the pre-kernel's sort implements)
+  h->fused = (cfg->schedule & (8 | 16)) == 0 && (cfg->schedule & 3) != 2;
+  if (h->fused) {
+    const int n = cfg->n_envs, G = (n + 63) / 64;
+    HIPCHK(h, hipMalloc(&h->mail, (size_t)n * CTRL_WORDS * sizeof(float)));
+    HIPCHK(h, hipMemset(h->mail, 0, (size_t)n * CTRL_WORDS * sizeof(float)));
+    HIPCHK(h, hipMalloc(&h->flags, (size_t)G * sizeof(int)));
+    HIPCHK(h, hipMemset(h->flags, 0, (size_t)G * sizeof(int)));
+    HIPCHK(h, hipMalloc(&h->errw, sizeof(int)));
+    HIPCHK(h, hipMemset(h->errw, 0, sizeof(int)));
+    if (cfg->schedule & 3) {
+      h->bin_ints = 64 + (size_t)64 * n;
+      HIPCHK(h, hipMalloc(&h->bins, 3 * h->bin_ints * sizeof(int)));
+      HIPCHK(h, hipMemset(h->bins, 0, 3 * h->bin_ints * sizeof(int)));
+    }
+  }
   if ((cfg->schedule & 3) == 2) {
     int cus = 0; HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     const int slots = 8 * cus;                    // two 256-VGPR wavefronts on each of the 4 SIMDs of a CU
@@ -479,6 +574,8 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
   }
   hipLaunchKernelGGL(pih_init_offsets_kernel, dim3((cfg->n_envs + 63) / 64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
   hipLaunchKernelGGL(pih_reset_kernel, dim3(cfg->n_envs), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0, 0);
+  // the first launch (epoch 1) reads bin buffer 1: every env once, ordered by the contact counts of the reset state
+  if (h->bins) hipLaunchKernelGGL(pih_bins_init_kernel, dim3(64), dim3(256), 0, 0, h->state, h->bins + h->bin_ints, cfg->n_envs);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipDeviceSynchronize());
   return 0;
@@ -542,7 +639,9 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
     t = &h->ev[h->ev_used++];
     HIPCHK(h, hipEventRecord(t->a, s));
   }
-  const bool lane_ctrl = (h->cfg.schedule & 8) != 0;      // measurement switch: the round 1-3 controller, one env per lane
+  // measurement switches.  peg-in-hole two-launch path: +8 = controller one env per lane, +16 = one env per quad.  random-fly: the
+  // default is the IK inside the one-env-per-lane step kernel; +16 = the quad-per-env pre-kernel (measured slower: tools/ik_bench.py)
+  const bool lane_ctrl = h->fly ? (h->cfg.schedule & 16) == 0 : (h->cfg.schedule & 8) != 0;
   if (h->fly) {   // controller (one env per quad of lanes), then physics (one env per lane)
     const dim3 grid((h->cfg.n_envs + 63) / 64); const size_t lds = (size_t)fly::LANE_WORDS * 64 * sizeof(float);
     if (!lane_ctrl) hipLaunchKernelGGL(pih_fly_pre_kernel, grid, dim3(256), 0, s, h->P, h->state, actions, h->cfg.n_envs);
@@ -553,11 +652,20 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
     HIPCHK(h, hipGetLastError());
     return 0;
   }
-  if (lane_ctrl) hipLaunchKernelGGL(pih_pre_lane_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs, h->sched_heads, h->sched_k);
-  else
-  hipLaunchKernelGGL(pih_pre_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs, h->sched_heads, h->sched_k);
-  if (t) HIPCHK(h, hipEventRecord(t->b, s));
-  hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, obs, reward, done, h->dbg, h->ovf, h->order);
+  FusedArgs F; memset(&F, 0, sizeof F);
+  if (h->fused) {
+    // one launch: controller wavefronts first, then the env wavefronts
+    const int e = ++h->epoch;
+    F.G = (h->cfg.n_envs + 63) / 64; F.n = h->cfg.n_envs; F.epoch = e; F.mail = h->mail; F.flags = h->flags; F.err = h->errw;
+    if (h->bins) { F.bcur = h->bins + (size_t)(e % 3) * h->bin_ints; F.bnext = h->bins + (size_t)((e + 1) % 3) * h->bin_ints; F.bzero = h->bins + (size_t)((e + 2) % 3) * h->bin_ints; }
+    if (t) HIPCHK(h, hipEventRecord(t->b, s));
+    hipLaunchKernelGGL(pih_step_kernel, dim3(F.G + h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->ovf, (const int*)nullptr, F);
+  } else {
+    if (lane_ctrl) hipLaunchKernelGGL(pih_pre_lane_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs, h->sched_heads, h->sched_k);
+    else hipLaunchKernelGGL(pih_pre_kernel, dim3(1 + (h->cfg.n_envs + 63) / 64), dim3(PRE_THREADS), 0, s, h->P, h->state, actions, h->order, h->cfg.n_envs, h->sched_heads, h->sched_k);
+    if (t) HIPCHK(h, hipEventRecord(t->b, s));
+    hipLaunchKernelGGL(pih_step_kernel, dim3(h->cfg.n_envs), dim3(64), 0, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->ovf, (const int*)h->order, F);
+  }
   if (t) HIPCHK(h, hipEventRecord(t->c, s));
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -686,6 +794,11 @@ int pih_timing2(pih_handle* h, int reset, double* pre_ms_out, double* step_ms_ou
   PIH_ENTER(h);
   int r = drain_events(h);
   if (r) return r;
+  if (h->errw) {     // (this call synchronises anyway) did an env wave of the fused launch give up waiting for its controller wavefront?
+    int ew = 0;
+    HIPCHK(h, hipMemcpy(&ew, h->errw, sizeof ew, hipMemcpyDeviceToHost));
+    if (ew) { h->err = "pih_step: an env wavefront timed out waiting for its controller wavefront (fused launch); results of that step are invalid"; return -5; }
+  }
   if (pre_ms_out) *pre_ms_out = h->acc_n ? h->acc_pre_ms / (double)h->acc_n : 0.0;
   if (step_ms_out) *step_ms_out = h->acc_n ? h->acc_step_ms / (double)h->acc_n : 0.0;
   if (launches_out) *launches_out = h->acc_n;

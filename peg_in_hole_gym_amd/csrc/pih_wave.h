@@ -35,6 +35,28 @@ struct Wave {
     else if (contacts > 10) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
   }
+  // Fused launch (pih_step_kernel with a controller role, round 4): the env's controller output arrives in a 16-word mailbox record,
+  // published by the controller wavefront of the env's group of 64 with a release store of the launch's epoch to the group's flag.
+  // Wave-uniform bounded wait (s_sleep between polls; on time-out the error word is set and the step proceeds with the targets it has --
+  // a launch can never hang on this), then the 13 controller words go into the LDS copy of the state record.  cmail == nullptr:
+  // two-launch path (pih_pre_kernel wrote the record before this kernel started), nothing to do.
+  const int* cflags = nullptr; const real* cmail = nullptr; int* cerr = nullptr; int cepoch = 0, cenv = 0;
+  PIH_HD void await_controller(Shared& sh) {
+    if (!cmail) return;
+    const int* f = cflags + (cenv >> 6);
+    int tries = 0;
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < cepoch) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++tries > (1 << 21)) { if (l == 0) atomicExch(cerr, 1); break; }
+    }
+    __syncthreads();
+    if (l < 13) {
+      const real v = cmail[(size_t)cenv * CTRL_WORDS + l];
+      const int word = l < 9 ? PIH_S_TARGET + l : (l == 9 ? (int)PIH_S_FSM : l == 10 ? (int)PIH_S_FSMT : l == 11 ? (int)PIH_S_GRASP_ANGLE : (int)PIH_S_ATTACH_QZ);
+      sh.S[word] = v;
+    }
+    __syncthreads();
+  }
   PIH_HD void sync() { __syncthreads(); }
   template <class F> PIH_HD void par(int n, F f) {
     __syncthreads();

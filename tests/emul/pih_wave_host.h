@@ -17,6 +17,7 @@ struct Wave {
   real du[ND];
   real hWmp[PIH_OBJ_NJ][WMS], hWma[9][9];               // motor response rows (the GPU keeps them in registers)
   void stamp(int) {}
+  void await_controller(Shared&) {}                     // (fused launch of the GPU build: nothing to wait for on the host)
 #ifdef PIH_COUNT_FLOPS
   void phase_begin() { g_phase_last = flop_counters(); }
   void phase(int k) {      // attribute the operations since the last mark to phase k (0 fk, 1 motor targets, 2 collide, 3 aba, 4 rows, 5 pgs, 6 integrate, 7 fk2)

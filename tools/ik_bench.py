@@ -51,5 +51,5 @@ if __name__ == "__main__":
         print("pih_ik n=%5d: %.1f us (20 iterations), %.1f us (10), %.1f us (0) -> %.2f us per iteration, %.0f cycles at 2.4 GHz" % (n, t20, t10, t0, (t20 - t10) / 10, (t20 - t10) / 10 * 2400))
     for task, name in ((0, "peg-in-hole"), (1, "random-fly")):
         for n in (1024, 4096, 16384):
-            q = time_pre(n, 1, task); l = time_pre(n, 9, task)
-            print("%s n=%5d: controller launch %.1f us + step kernel %.1f us with one env per QUAD; %.1f us + %.1f us with one env per LANE (schedule bit 3)" % (name, n, q[0], q[1], l[0], l[1]))
+            f = time_pre(n, 1, task); q = time_pre(n, 1 + 16, task); l = time_pre(n, 1 + 8, task)
+            print("%s n=%5d: default (peg-in-hole: ONE fused launch) %.1f + %.1f us; two launches, controller one env per QUAD %.1f + %.1f us; one env per LANE %.1f + %.1f us" % (name, n, f[0], f[1], q[0], q[1], l[0], l[1]))
