@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __rest
   const int lane = threadIdx.x;
   if ((int)blockIdx.x < F.G) {
     // ---- controller role: 64 envs, one per lane (controller_compute: the strictly sequential IK)
+    __builtin_amdgcn_s_setprio(3);                             // it shares its SIMD with an env wavefront that will be waiting for it
     if (blockIdx.x == 0 && F.bzero) F.bzero[lane] = 0;
     const int env = blockIdx.x * 64 + lane;
     if (env < F.n) {
@@ -130,13 +131,14 @@ __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __rest
         if (actions) { a[0] = actions[env * 4]; a[1] = actions[env * 4 + 1]; a[2] = actions[env * 4 + 2]; a[3] = actions[env * 4 + 3]; }
         const CtrlOut o = controller_compute(S, P, a);
         float* m = F.mail + (size_t)env * CTRL_WORDS;
+        const float ov[13] = {o.target[0], o.target[1], o.target[2], o.target[3], o.target[4], o.target[5], o.target[6], o.target[7], o.target[8], o.fsm, o.fsmt, o.grasp_angle, o.attach_qz};
 #pragma unroll
-        for (int i = 0; i < 9; i++) m[i] = o.target[i];
-        m[9] = o.fsm; m[10] = o.fsmt; m[11] = o.grasp_angle; m[12] = o.attach_qz;
+        for (int i = 0; i < 13; i++) __hip_atomic_store(m + i, ov[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the mailbox stores of all 64 lanes are acknowledged ...
     __syncthreads();
-    if (lane == 0) __hip_atomic_store(F.flags + blockIdx.x, F.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(F.flags + blockIdx.x, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the group is published
     return;
   }
   __shared__ Shared sh;

@@ -45,13 +45,18 @@ struct Wave {
     if (!cmail) return;
     const int* f = cflags + (cenv >> 6);
     int tries = 0;
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < cepoch) {
+    // (flag and mailbox words are RELAXED agent-scope atomics: loads and stores that are coherent across the chip's eight L2s by
+    //  themselves.  An agent-scope acquire would invalidate, and a release write back, the whole L2 of the XCD -- measured: + 50 us per
+    //  launch with 4 096 acquires.  Order: the controller completes its mailbox stores (workgroup-scope release fence = wait for the
+    //  stores to be acknowledged) before it stores the flag; this wave reads the mailbox after it has seen the flag.)
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < cepoch) {
       __builtin_amdgcn_s_sleep(4);
       if (++tries > (1 << 21)) { if (l == 0) atomicExch(cerr, 1); break; }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     __syncthreads();
     if (l < 13) {
-      const real v = cmail[(size_t)cenv * CTRL_WORDS + l];
+      const real v = __hip_atomic_load(cmail + (size_t)cenv * CTRL_WORDS + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int word = l < 9 ? PIH_S_TARGET + l : (l == 9 ? (int)PIH_S_FSM : l == 10 ? (int)PIH_S_FSMT : l == 11 ? (int)PIH_S_GRASP_ANGLE : (int)PIH_S_ATTACH_QZ);
       sh.S[word] = v;
     }
