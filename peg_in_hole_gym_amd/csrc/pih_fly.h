@@ -6,7 +6,7 @@
 //   reset_state       init_ur / reset_ur + random_pos_in_panda_space                              envs/utils.py:40-48,55-57,97-107
 //   step_env          p.stepSimulation for the UR5 (ur5.urdf) and the object (banana.urdf)        envs/base_env.py:64
 // The task CLASS is not in the reference snapshot (TASK_LIST holds only 'peg-in-hole', envs/base_env.py:9-11): rest pose, launch
-// law, reward / done and the observation are BUILD-DEFINED (DESIGN.md section 9, same definitions as oracle/pih_fly_oracle.c).
+// law, reward / done and the observation are BUILD-DEFINED (DESIGN.md section 6.4, same definitions as oracle/pih_fly_oracle.c).
 //
 // Mapping: the system is 12 DOF (6 arm joints + a free rigid body) with at most 10 frictionless contacts -- far too little
 // parallel work for a wavefront per env -- and its dominant cost is the 20 strictly sequential 6x6 DLS solves of the IK.  So

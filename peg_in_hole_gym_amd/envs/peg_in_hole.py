@@ -16,8 +16,15 @@ def _objects_from_model_header():
     import os
     import re
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "include", "pih_model.h")
-    m = re.search(r"#define PIH_FLY_OBJ_NAMES \{([^}]*)\}", open(hdr).read())
-    return tuple(re.findall(r'"([^"]+)"', m.group(1)))
+    try:
+        m = re.search(r"#define PIH_FLY_OBJ_NAMES \{([^}]*)\}", open(hdr).read())
+        names = tuple(re.findall(r'"([^"]+)"', m.group(1)))
+    except (OSError, AttributeError) as ex:
+        raise ImportError("peg_in_hole_gym_amd: cannot read the object table PIH_FLY_OBJ_NAMES from %s (%r); regenerate it with "
+                          "tools/gen_model_header.py" % (hdr, ex)) from ex
+    if not names:
+        raise ImportError("peg_in_hole_gym_amd: PIH_FLY_OBJ_NAMES in %s is empty" % hdr)
+    return names
 
 
 class MetaEnv(object):
@@ -111,7 +118,7 @@ class RandomFly(MetaEnv):
     """'random-fly' (README.md:38: task='random-fly', args=['Banana', 1/120.]): the UR5 of assets/urdf/ur5.urdf driven by
     ur_execute (envs/utils.py:70-82) next to one free-flying object spawned by random_pos_in_panda_space (envs/utils.py:97-107).
     The task class is not in the reference snapshot; rest pose, launch law, reward / done and observation are build-defined
-    (DESIGN.md section 9).  args[0] = object name -- one of OBJECTS, the single-link free bodies under envs/assets/urdf that
+    (DESIGN.md section 6.4).  args[0] = object name -- one of OBJECTS, the single-link free bodies under envs/assets/urdf that
     tools/gen_model_header.py turned into tables of include/pih_model.h (PIH_FLY_OBJ_NAMES: 'Banana', 'Amicelli'); its index is the
     library's pih_config.object_id -- args[1] = physics time step."""
     action_space = Box(np.array([-1] * 6), np.array([1] * 6))       # ee target xyz + euler rpy (envs/utils.py:71-72)

@@ -66,8 +66,8 @@ def random_pos_in_panda_space():
 def ur_execute(backend, q, action, position_gain=0.03, max_force=300.0):
     """Host mirror of ur_execute (envs/utils.py:70-82) for a batch: pos = action[:, :3], orn = quat(euler(action[:, 3:6])),
     jointPoses = calculateInverseKinematics(ur, ee, pos, orn) on the GPU (pih_ik_ur5).  Returns (jointPoses [n,6],
-    positionGains, forces) -- what the reference hands to setJointMotorControlArray.  (The UR5 dynamics are not part of
-    this build; the task that uses this controller does not exist in the reference snapshot.)"""
+    positionGains, forces) -- what the reference hands to setJointMotorControlArray.  (Stand-alone helper: inside the 'random-fly'
+    task (task_id 1, peg_in_hole_gym_amd/csrc/pih_fly.h) the same controller and the UR5 dynamics run on the device.)"""
     import torch
     a = torch.as_tensor(action, dtype=torch.float32)
     r, p, y = a[:, 3] * 0.5, a[:, 4] * 0.5, a[:, 5] * 0.5

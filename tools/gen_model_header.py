@@ -15,8 +15,9 @@ Sources (reference paths relative to /root/reference/peg_in_hole_gym/):
   * free bodies: envs/assets/urdf/banana.urdf:1-32 + obj/banana_collision.obj (5 convex hulls) and
             envs/assets/urdf/Amicelli_800_tex.urdf:1-33 + obj/Amicelli_800_tex.obj (one closed mesh) -- the free-flying objects
             of the 'random-fly' task, selected by args[0] (README.md:38: args=['Banana', 1/120.]).
-  * charge_board: envs/assets/urdf/charge_board.urdf:1-40 (fixed base + one hinged door, primitive cylinder): tables only (no task
-            of the snapshot uses it).
+  * charge_board: envs/assets/urdf/charge_board.urdf:1-40 (fixed base + one hinged door, primitive cylinder) is READ by
+            tools/urdf_tables.hinged_body_tables (tested) but no longer emitted: nothing of the reference loads it and no kernel
+            consumed the PIH_DOOR_* tables of round 3.
 
 Everything that exists in the reference tree is READ from it (tools/urdf_tables.py: URDF via xml.etree, fixed-joint merge,
 globalScaling, OBJ / binary-STL collision meshes for the AABB box-inertia rule); only the Panda and the table, whose assets
@@ -41,7 +42,6 @@ PIPE = UT.pipe_tables(REF)
 HOLE = UT.hole_tables(REF)
 UR5 = UT.ur5_tables(REF)
 OBJECTS = [UT.free_body_tables(REF, f) for f in UT.FLY_OBJECT_FILES]
-DOOR = UT.hinged_body_tables(REF)
 MARGIN = 0.001          # pybullet's default collision margin for URDF meshes [UNVERIFIED, SURVEY.md App. C]
 DEFAULT_MU = 0.5        # pybullet's default lateral friction for links without a <contact> block
 
@@ -329,20 +329,4 @@ print("#define PIH_FLY_OBJ_NSPH " + iarr(len(o["sphere_r"]) for o in OBJECTS))
 print("#define PIH_FLY_OBJ_SPH_C {" + ", ".join("{" + ", ".join(arr(np.round(c, 9)) for c in (o["sphere_c"] + [[0.0, 0.0, 0.0]] * MAXSPH)[:MAXSPH]) + "}" for o in OBJECTS) + "}")
 print("#define PIH_FLY_OBJ_SPH_R {" + ", ".join(arr(round(r, 9) for r in (o["sphere_r"] + [0.0] * MAXSPH)[:MAXSPH]) for o in OBJECTS) + "}")
 print("#define PIH_FLY_OBJ_RGB {" + ", ".join(arr(o["rgba"][:3]) for o in OBJECTS) + "}   /* <material> colour */")
-# ----------------------------------------------------------------------------- charge_board.urdf (tables only)
-print("/* envs/assets/urdf/charge_board.urdf:1-40: fixed base + ONE hinged door (no task of the snapshot loads it; emitted so that the reader")
-print(" * is exercised on a revolute joint with limits / damping and a primitive <cylinder>): hinge in the base frame, door mass, inertia by")
-print(" * pybullet's AABB rule next to the file's values, the cylinder in the door frame */")
-print("#define PIH_DOOR_BASE_T " + arr(DOOR["base_xyz"]))
-print("#define PIH_DOOR_HINGE_T " + arr(DOOR["hinge_xyz"]))
-print("#define PIH_DOOR_HINGE_AXIS " + arr(DOOR["hinge_axis"]))
-print("#define PIH_DOOR_LO %s" % fmt(DOOR["lower"]))
-print("#define PIH_DOOR_HI %s" % fmt(DOOR["upper"]))
-print("#define PIH_DOOR_DAMPING %s" % fmt(DOOR["damping"]))
-print("#define PIH_DOOR_MASS %s" % fmt(DOOR["mass"]))
-print("#define PIH_DOOR_INERTIA " + arr(DOOR["inertia_rule"]) + "   /* AABB rule; the file says " + arr(DOOR["inertia_file"]) + " */")
-print("#define PIH_DOOR_CYL_C " + arr(DOOR["cyl_xyz"]))
-print("#define PIH_DOOR_CYL_AXIS " + arr(DOOR["cyl_axis"]))
-print("#define PIH_DOOR_CYL_R %s" % fmt(DOOR["cyl_radius"]))
-print("#define PIH_DOOR_CYL_HALFLEN %s" % fmt(0.5 * DOOR["cyl_length"]))
 print("#endif")
