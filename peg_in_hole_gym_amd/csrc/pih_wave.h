@@ -562,8 +562,9 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       z = rhs + v;                         // (Bn = [own] - dinv A: the sum is  [own normal row] lam0 - dinv (J du))
     }
     real amax = 0;                           // largest |multiplier| any arm motor row 0..6 took during the solve (limit rows left out)
-    auto iterate = [&](auto CHECKTAG) __attribute__((always_inline)) -> bool {
+    auto iterate = [&](auto CHECKTAG, auto WELDTAG) __attribute__((always_inline)) -> bool {
       constexpr bool CHECK = decltype(CHECKTAG)::value;     // evaluate the early-exit test in this iteration? (see pgs_iteration_loop)
+      constexpr bool WELD = decltype(WELDTAG)::value;       // attach / weld rows present (scripted mode): see pgs_rows2
       unsigned long long busy = 0;
       __asm__ volatile("" ::: "memory");      // keep the arm row constants in LDS (see pgs(): LICM would hoist and spill them)
       constexpr int PF = 4;
@@ -629,8 +630,8 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
         gs_row1_normal(z, Bn[g0], lbv, lam, g0, dl, s0);
         if (CHECK) busy |= __ballot(absr(dl) > thr) & (1ull << g0);
         // wave-uniform branch on  s0 > 0 || weld row  (as integers, on the scalar unit: see pgs_rows2)
-        const int s0i = __builtin_bit_cast(int, s0), weld = (int)((am >> c) & 1u);
-        if ((s0i > weld ? s0i : weld) > 0) {
+        const int s0i = __builtin_bit_cast(int, s0), weld = WELD ? (int)((am >> c) & 1u) : 0;
+        if (WELD ? (s0i > weld ? s0i : weld) > 0 : s0i > 0) {
           const real hi = max_(cmu * s0, cfl);
           real dl2;
           gs_row1_friction2(z, Bn[g0 + 1], Bn[g0 + 2], hi, lam, g0 + 1, g0 + 2, dl, dl2);
@@ -639,7 +640,8 @@ PIH_HD int pgs_rows(Wave& w, Shared& sh, const Params& P) {
       }
       return CHECK && busy == 0;
     };
-    it = pgs_iteration_loop(P.iters, P.checkstride, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
+    if (angmask != 0) it = pgs_iteration_loop(P.iters, P.checkstride, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}, std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}, std::true_type{}); });
+    else it = pgs_iteration_loop(P.iters, P.checkstride, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}, std::false_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}, std::false_type{}); });
     return __builtin_amdgcn_readfirstlane(amax >= armlim ? 1 : 0) != 0;   // (armlim = the smallest bound of rows 0..6: conservative if they differ, exact if equal)
   };
   int variant = 1;
@@ -833,8 +835,12 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
 #pragma unroll
   for (int j = 0; j < 9; j++) { lam_a[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
   z0 = c0.rhs + wv0; z1 = c1.rhs + wv1;                      // warm start: z = lambda + rhs - dinv (J du) (see pgs_rows)
-  auto iterate = [&](auto CHECKTAG) __attribute__((always_inline)) -> bool {
+  // WELD: the env has attach / weld rows (scripted mode, states 4-6), whose friction rows run whatever the normal multiplier is; without
+  // them (always in action mode) the per-contact test is a scalar compare of s0's bit pattern alone.  (Round 4: one instantiation per
+  // case; the combined test had come out as five instructions -- v_and, v_max_i32, v_cmp, s_and, s_cbranch -- per contact.)
+  auto iterate = [&](auto CHECKTAG, auto WELDTAG) __attribute__((always_inline)) -> bool {
     constexpr bool CHECK = decltype(CHECKTAG)::value;
+    constexpr bool WELD = decltype(WELDTAG)::value;
     unsigned long long busy = 0;
     __asm__ volatile("" ::: "memory");
     // ring of streamed columns: the first D are requested before the motor rows
@@ -899,17 +905,19 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
       for (int k = 0; k < 3; k++) {
         const int sc = g0 + k - KREG;                        // (KREG = NMOT: every contact column is streamed)
         bb[k] = rr[sc % D];
-        rr[sc % D] = *(gpp)(colq + k * 512 + l8c);         // request the column a ring ahead
+        rr[sc % D] = *(gpp)(colq + ((c & 1) * 3 + k) * 512 + l8c);   // request the column a ring ahead (immediate offsets 0 .. 2 560)
       }
-      colq += 3 * 512;
-      __asm__ volatile("" : "+s"(colq));                   // (the running pointer stays in an SGPR pair: s_add_u32 / s_addc_u32 per contact)
+      if (c & 1) {
+        colq += 6 * 512;
+        __asm__ volatile("" : "+s"(colq));                 // (the running pointer stays in an SGPR pair: s_add_u32 / s_addc_u32 per PAIR of contacts)
+      }
       real dl, s0;
       if (g0 < 64) { gs_row2_normal(zz, pk_lo(zz), bb[0], c0.lb, lam0, g0, dl, s0); if (CHECK) busy |= __ballot(absr(dl) > c0.thr) & (1ull << g0); }
       else { gs_row2_normal(zz, pk_hi(zz), bb[0], c1.lb, lam1, g0 - 64, dl, s0); if (CHECK) busy |= __ballot(absr(dl) > c1.thr) & (1ull << (g0 - 64)); }
       // Bullet leaves the friction rows of an unloaded contact alone: wave-uniform branch on  s0 > 0 || weld row  -- as integers, on
       // the scalar unit (the bit pattern of a positive float is a positive integer)
-      const int s0i = __builtin_bit_cast(int, s0), weld = (int)((am >> c) & 1u);
-      if ((s0i > weld ? s0i : weld) > 0) {
+      const int s0i = __builtin_bit_cast(int, s0), weld = WELD ? (int)((am >> c) & 1u) : 0;
+      if (WELD ? (s0i > weld ? s0i : weld) > 0 : s0i > 0) {
         auto friction = [&](int g, pk2 col) __attribute__((always_inline)) {      // (row g lives in register set g / 64)
           if (g < 64) { const real h0 = max_(c0.mu * s0, c0.fl); gs_row2_friction(zz, pk_lo(zz), col, h0, lam0, g, dl); if (CHECK) busy |= __ballot(absr(dl) > c0.thr) & (1ull << g); }
           else { const real h1 = max_(c1.mu * s0, c1.fl); gs_row2_friction(zz, pk_hi(zz), col, h1, lam1, g - 64, dl); if (CHECK) busy |= __ballot(absr(dl) > c1.thr) & (1ull << (g - 64)); }
@@ -921,7 +929,9 @@ PIH_HD int pgs_rows2(Wave& w, Shared& sh, const Params& P, const Ovf& ov, const 
     z0 = pk_lo(zz); z1 = pk_hi(zz);
     return CHECK && busy == 0;
   };
-  const int it = pgs_iteration_loop<false>(P.iters, P.checkstride, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}); });
+  int it;
+  if (angmask != 0) it = pgs_iteration_loop<false>(P.iters, P.checkstride, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}, std::true_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}, std::true_type{}); });
+  else it = pgs_iteration_loop<false>(P.iters, P.checkstride, [&]() __attribute__((always_inline)) { return iterate(std::true_type{}, std::false_type{}); }, [&]() __attribute__((always_inline)) { return iterate(std::false_type{}, std::false_type{}); });
   if (lane == 0) sh.S[PIH_S_SOLVER] = 5;
   // ---- multipliers back to LDS, DOF velocities du = sum_i W_i lambda_i
   if (lane >= NMOT && lane < NMOT + 3 * nc) sh.r_lam[lane - NMOT] = lam0;
