@@ -9,6 +9,9 @@ dt 1/240, auto-reset.  The envs are PRE-ROLLED to contact steady state (--prerol
 pipes have landed, the grippers wander at table height) before --warmup and the timed --steps, so that a short run measures
 the same contact load as a long one (`sanity.mean_contacts` is the average over the start and the end of the timed region).
 
+Since round 4 a peg-in-hole step is ONE launch (pih_step_kernel: controller wavefronts + env wavefronts; --schedule 9 / 17 select the
+two-launch step of rounds 1-3 for A/B runs), so `kernel_avg_ms` contains the controller and `pre_kernel_avg_ms` is only the gap between launches.
+
 N GPUs: `python bench.py --gpus N` with WORLD_SIZE unset starts N ranks itself (torch.distributed.run, before anything touches
 the GPU) and relays rank 0's JSON line; under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  One process per GPU, envs
 block-partitioned, the stacked observation all-gathered over RCCL each step.  Default = weak scaling
@@ -408,7 +411,11 @@ def main():
                        "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + %s all-gather(obs)" % ("RCCL" if args.backend == "nccl" and use_gpu else "gloo"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (alg_bytes * n),
-                         "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel", "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches, "event_stride": args.timing_stride,
+                         "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel",
+                         "launches_per_step": ("one: pih_fly_step_kernel, IK inside" if not (args.schedule & 16) else "two: pih_fly_pre_kernel (IK, one env per quad of lanes) + pih_fly_step_kernel") if fly else
+                                              ("two: pih_pre_kernel (controller) + pih_step_kernel" if (args.schedule & 24) or (args.schedule & 3) == 2 else
+                                               "one: pih_step_kernel = controller wavefronts + env wavefronts (fused launch); pre_kernel_avg_ms is the gap between two launches"),
+                         "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches, "event_stride": args.timing_stride,
                          "alg_bytes_per_env_step": alg_bytes, "valu_issue": vi, "frac_valu_issue": vi["frac_valu_issue"] if vi else None, "frac_valu_issue_launch_wide": vi["launch_wide"] if vi else None, "flops": flops, "note": note},
             "sanity": {"state_finite": finite, "mean_contacts": 0.5 * (c_start + c_end), "mean_contacts_start": c_start, "mean_contacts_end": c_end,
                        "pgs_variant_share": variants,

@@ -338,6 +338,11 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
   extern __shared__ float lanemem[];
   const int env = blockIdx.x * 64 + threadIdx.x;
   if (env >= n) return;
+  // config.debug = 2: start / end of the wavefront on the chip-wide 100 MHz clock and where it ran (debug words 940 .. 947 of the wave's
+  // first env; tools/fly_trace.py) -- never read by the kernel
+  const bool stamp = dbg && P.debug == 2 && threadIdx.x == 0;
+  long long ts0 = 0;
+  if (stamp) ts0 = (long long)__builtin_amdgcn_s_memrealtime();
   float S[fly::SW];
 #pragma unroll
   for (int w = 0; w < fly::SW; w++) S[w] = state[(size_t)w * n + env];
@@ -357,6 +362,13 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
   }
   if (reward) reward[env] = r;
   if (done) done[env] = d;
+  if (stamp) {
+    const long long ts1 = (long long)__builtin_amdgcn_s_memrealtime();
+    float* o = dbg + (size_t)env * PIH_DEBUG_WORDS;
+    o[940] = (float)(ts0 & 0xFFFF); o[941] = (float)((ts0 >> 16) & 0xFFFF); o[942] = (float)((ts0 >> 32) & 0xFFFF);
+    o[943] = (float)(ts1 & 0xFFFF); o[944] = (float)((ts1 >> 16) & 0xFFFF); o[945] = (float)((ts1 >> 32) & 0xFFFF);
+    o[946] = (float)(__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xFFFF); o[947] = (float)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+  }
 }
 
 __global__ void __launch_bounds__(64) pih_fly_reset_kernel(Params P, float* __restrict__ state, const unsigned char* __restrict__ mask, int hard, int rewind, int n) {

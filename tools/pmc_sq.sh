@@ -41,14 +41,14 @@ for f in glob.glob("gpurun_out/sq_%s%s_[0-9]/**/*counter_collection.csv" % (tag,
     for r in csv.DictReader(open(f)):
         if kernel in r["Kernel_Name"]:
             if p4:
-                per.setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
+                per.setdefault(r["Dispatch_Id"], {"dur": float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))})[r["Counter_Name"]] = float(r["Counter_Value"])
                 if r["Counter_Name"] != "GRBM_GUI_ACTIVE":
                     continue
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    span += [(d["GRBM_GUI_ACTIVE"], d["SQ_ACTIVE_INST_VALU"]) for d in per.values() if "GRBM_GUI_ACTIVE" in d and "SQ_ACTIVE_INST_VALU" in d]
+    span += [(d["GRBM_GUI_ACTIVE"], d["SQ_ACTIVE_INST_VALU"], d["dur"]) for d in per.values() if "GRBM_GUI_ACTIVE" in d and "SQ_ACTIVE_INST_VALU" in d]
 for k, v in sorted(acc.items()):
     out[k] = sum(v) / len(v)
-n_envs = 4096
+n_envs = 4096          # (bench.py's default batch; the fused launch adds 64 controller wavefronts to SQ_WAVES, their instructions are part of the step)
 if "SQ_INSTS_VALU" in out:
     out["valu_insts_per_env_step"] = out["SQ_INSTS_VALU"] / n_envs
 if all(k in out for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")):
@@ -60,11 +60,15 @@ if w:
             out["frac_" + k] = out[k] / w
 if span:
     # SQ_ACTIVE_INST_VALU counts quad-cycles (x 4 = cycles) summed over all waves; the chip has 256 CUs x 4 SIMDs, each of which can have ONE
-    # VALU instruction in flight: launch-wide fraction of the VALU issue capacity = sum / (1024 SIMDs x span in cycles)
+    # VALU instruction in flight: launch-wide fraction of the VALU issue capacity = sum / (1024 SIMDs x span in cycles).
+    # GRBM_GUI_ACTIVE is summed over the chip's 8 XCDs: / 8 = the dispatch's span in engine clocks (check: span / (End - Start timestamp
+    # of the same dispatch) = 2.42 GHz on the MI355X, the engine clock -- recorded as `span_clock_ghz`)
     tail = span[len(span) // 2:]          # the later dispatches of the run (contact steady state)
-    out["n_simds"] = 1024
-    out["launch_wide_valu_issue"] = sum(4.0 * v / (1024.0 * g) for g, v in tail) / len(tail)
-    out["launch_span_cycles"] = sum(g for g, _ in tail) / len(tail)
+    out["n_simds"] = 1024; out["n_xcd"] = 8
+    out["launch_wide_valu_issue"] = sum(4.0 * v / (1024.0 * g / 8.0) for g, v, _ in tail) / len(tail)
+    out["launch_span_cycles"] = sum(g / 8.0 for g, _, _ in tail) / len(tail)
+    out["launch_span_ns"] = sum(d for _, _, d in tail) / len(tail)
+    out["span_clock_ghz"] = out["launch_span_cycles"] / out["launch_span_ns"]
 json.dump(out, open("gpurun_out/sq_%s%s.json" % (tag, suf), "w"), indent=1)
 print(json.dumps(out))
 PY

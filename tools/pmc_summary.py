@@ -22,6 +22,18 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     out[c.lower() + "_kib"] = sum(vals) / len(vals) if vals else None
     out[c.lower() + "_launches"] = len(vals)
     out["n_envs"] = grid // lanes_per_env if grid else None
+    if out["n_envs"] and not fly:
+        # the fused launch (round 4) has ceil(n / 64) controller wavefronts in front of the n env wavefronts: blocks = n + ceil(n / 64)
+        blocks = out["n_envs"]; n = blocks
+        while n > 0 and n + (n + 63) // 64 > blocks:
+            n -= 1
+        try:
+            bj = json.loads(open(os.path.join(root, "gpurun_out", "pmc_%s%s_%s.bench.json" % (tag, suf, c))).read().strip().splitlines()[-1])
+            if bj["config"]["envs_per_gpu"] in (n, blocks):
+                n = bj["config"]["envs_per_gpu"]
+        except Exception:  # noqa: BLE001
+            pass
+        out["n_envs"] = n; out["blocks"] = blocks
 if out.get("fetch_size_kib") is not None and out.get("write_size_kib") is not None:
     out["traffic_raw"] = (out["fetch_size_kib"] + out["write_size_kib"]) * 1024
     out["traffic_fetch_x2"] = (2 * out["fetch_size_kib"] + out["write_size_kib"]) * 1024
