@@ -153,7 +153,9 @@ int pih_reset(pih_handle* h, const uint8_t* mask_dev, int hard, uint64_t seed, v
  * `seed` to that call: it must reset all envs, mask_dev = NULL, and returns -2 otherwise) */
 int pih_reseed(pih_handle* h, uint64_t seed);
 /* actions_dev float[n,4]; obs_dev float[n,5]; reward_dev float[n]; done_dev uint8[n]
- * (PIH_TASK_RANDOM_FLY: actions float[n,6], obs float[n,6]) */
+ * (PIH_TASK_RANDOM_FLY: actions float[n,6], obs float[n,6]).
+ * peg-in-hole: ONE kernel launch (controller wavefronts + env wavefronts; pih_config.schedule + 8 / + 16: the two launches of rounds 1-3).
+ * Returns -5 (and keeps returning it) if in an earlier step of this handle an env wavefront timed out waiting for its controller wavefront. */
 int pih_step(pih_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 /* k consecutive steps with the same action buffer (scripted mode ignores actions: may be NULL) in one call */
 int pih_step_n(pih_handle* h, int k, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);

@@ -125,6 +125,11 @@ class Oracle:
             setattr(v, k, x)
         self.L.piho_set_variant(C.c_void_p(self.h), C.byref(v))
 
+    def round_state_fp32(self, rel=0.0, seed=0, tick=0):
+        """state record + warm-start cache through fp32, in place (optionally the 77 position / velocity words perturbed by rel U(-1, 1) first)"""
+        self.L.piho_round_state_fp32.argtypes = [C.c_void_p, C.c_float if self.real is np.float32 else C.c_double, C.c_uint64, C.c_uint64]
+        self.L.piho_round_state_fp32(C.c_void_p(self.h), float(rel), int(seed), int(tick))
+
     def debug_friction(self):
         """(friction multipliers [n, CMAX, 2], number of clamped coordinate velocities [n]) of the last step"""
         lt = np.zeros((self.n, CMAX, 2), self.real); nc = np.zeros(self.n, dtype=np.int32)

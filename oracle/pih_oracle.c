@@ -1173,6 +1173,24 @@ void piho_grasp_labels(real angle, int S, real* out, real* meta /* x, y, angle_d
 
 /* ------------------------------------------------------------------------------------------ accessors */
 void piho_get_state(const piho_handle* h, real* out) { for (int e = 0; e < h->cfg.n_envs; e++) memcpy(out + (size_t)e * PIHO_STATE_WORDS, h->env[e].s, sizeof(real) * PIHO_STATE_WORDS); }
+/* Test helper (tests/parity_util.py first_exceedance_run: the yardsticks of the acceptance run): pass every env's state record and warm-start
+ * cache through fp32 -- what the product's HBM record holds between steps -- and, rel > 0, multiply the 77 position / velocity words by
+ * 1 + rel U(-1, 1) first (counter RNG keyed by seed, env and `tick`).  In place: the same as get_state / set_state / set_warm_cache
+ * from Python, without four 4-MB copies per step. */
+void piho_round_state_fp32(piho_handle* h, real rel, uint64_t seed, uint64_t tick) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int e = 0; e < h->cfg.n_envs; e++) {
+    Env* E = &h->env[e];
+    if (rel > 0) for (int i = 0; i < 77; i++) E->s[i] *= 1 + rel * (2.0 * (real)rng24(seed + 7919ULL * (uint64_t)e, tick * 128 + (uint64_t)i) / 16777216.0 - 1.0);
+    for (int i = 0; i < PIHO_STATE_WORDS; i++) E->s[i] = (real)(float)E->s[i];
+    for (int k = 0; k < E->ncache; k++) E->cache_lambda[k] = (real)(float)E->cache_lambda[k];
+    LinkKin K[NL];
+    fk(&E->s[PIHO_S_QARM], &E->s[PIHO_S_POS], &E->s[PIHO_S_QUAT], &E->s[PIHO_S_QJ], ANL, NL, K);
+    tip_pose(E, K, E->tip);
+  }
+}
 void piho_set_state(piho_handle* h, const real* in) {
   for (int e = 0; e < h->cfg.n_envs; e++) {
     Env* E = &h->env[e];

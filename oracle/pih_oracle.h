@@ -100,6 +100,8 @@ void piho_debug_contacts_all(const piho_handle* h, piho_real* out, int32_t* coun
 void piho_step(piho_handle* h, const piho_real* actions, piho_real* obs, piho_real* reward, uint8_t* done);
 void piho_get_state(const piho_handle* h, piho_real* out /* [n,128] */);
 void piho_set_state(piho_handle* h, const piho_real* in /* [n,128] */);   /* also clears the warm-start cache */
+/* test helper: state record + warm-start cache through fp32 in place (the product's record between steps), optionally perturbed first */
+void piho_round_state_fp32(piho_handle* h, piho_real rel, uint64_t seed, uint64_t tick);
 void piho_get_tip_pose(const piho_handle* h, piho_real* out /* [n,7] */);
 void piho_get_contact_force(const piho_handle* h, piho_real* out /* [n] sum of normal impulses / dt of the last step */);
 void piho_get_ncontacts(const piho_handle* h, int32_t* out /* [n] */);

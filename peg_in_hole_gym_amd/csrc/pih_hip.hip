@@ -444,7 +444,7 @@ struct pih_handle {
   // fused launch (default for the peg-in-hole task): controller mailbox + group flags + error word, three rotating bin buffers of the
   // in-kernel dispatch order, the launch counter
   bool fused = false;
-  float* mail = nullptr; int* flags = nullptr; int* errw = nullptr; int* bins = nullptr; size_t bin_ints = 0; int epoch = 0;
+  float* mail = nullptr; int* flags = nullptr; int* errw = nullptr; volatile int* errw_host = nullptr; int* bins = nullptr; size_t bin_ints = 0; int epoch = 0;
   std::string err;
   int timing = 0;           // 0 off; k >= 1: every k-th step launch is bracketed by events (pih_set_timing)
   unsigned timing_tick = 0;
@@ -454,6 +454,7 @@ struct pih_handle {
 };
 
 static thread_local std::string g_err;
+static const char* const CTRL_TIMEOUT_MSG = "pih_step: an env wavefront timed out waiting for its controller wavefront (fused launch); the results of that step are invalid";
 
 static int fail(pih_handle* h, const char* what, hipError_t e) {
   std::string m = std::string(what) + ": " + hipGetErrorString(e);
@@ -531,7 +532,7 @@ int pih_destroy(pih_handle* h) {
   if (h->order) hipFree(h->order);
   if (h->mail) hipFree(h->mail);
   if (h->flags) hipFree(h->flags);
-  if (h->errw) hipFree(h->errw);
+  if (h->errw_host) hipHostFree(const_cast<int*>(h->errw_host));
   if (h->bins) hipFree(h->bins);
   delete h;
   return 0;
@@ -572,8 +573,11 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
     HIPCHK(h, hipMemset(h->mail, 0, (size_t)n * CTRL_WORDS * sizeof(float)));
     HIPCHK(h, hipMalloc(&h->flags, (size_t)G * sizeof(int)));
     HIPCHK(h, hipMemset(h->flags, 0, (size_t)G * sizeof(int)));
-    HIPCHK(h, hipMalloc(&h->errw, sizeof(int)));
-    HIPCHK(h, hipMemset(h->errw, 0, sizeof(int)));
+    // the error word lives in pinned, device-mapped HOST memory: an env wavefront that gives up waiting stores 1 there (system scope), and
+    // the next pih_step / pih_timing2 on the handle sees it without synchronising anything
+    HIPCHK(h, hipHostMalloc((void**)&h->errw_host, sizeof(int), hipHostMallocMapped));
+    *h->errw_host = 0;
+    HIPCHK(h, hipHostGetDevicePointer((void**)&h->errw, const_cast<int*>(h->errw_host), 0));
     if (cfg->schedule & 3) {
       h->bin_ints = 64 + (size_t)64 * n;
       HIPCHK(h, hipMalloc(&h->bins, 3 * h->bin_ints * sizeof(int)));
@@ -668,6 +672,7 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
   }
   FusedArgs F; memset(&F, 0, sizeof F);
   if (h->fused) {
+    if (*h->errw_host) { h->err = CTRL_TIMEOUT_MSG; return -5; }     // an EARLIER step of this handle timed out: fail loudly from here on
     // one launch: controller wavefronts first, then the env wavefronts
     const int e = ++h->epoch;
     F.G = (h->cfg.n_envs + 63) / 64; F.n = h->cfg.n_envs; F.epoch = e; F.mail = h->mail; F.flags = h->flags; F.err = h->errw;
@@ -808,11 +813,7 @@ int pih_timing2(pih_handle* h, int reset, double* pre_ms_out, double* step_ms_ou
   PIH_ENTER(h);
   int r = drain_events(h);
   if (r) return r;
-  if (h->errw) {     // (this call synchronises anyway) did an env wave of the fused launch give up waiting for its controller wavefront?
-    int ew = 0;
-    HIPCHK(h, hipMemcpy(&ew, h->errw, sizeof ew, hipMemcpyDeviceToHost));
-    if (ew) { h->err = "pih_step: an env wavefront timed out waiting for its controller wavefront (fused launch); results of that step are invalid"; return -5; }
-  }
+  if (h->errw_host && *h->errw_host) { h->err = CTRL_TIMEOUT_MSG; return -5; }
   if (pre_ms_out) *pre_ms_out = h->acc_n ? h->acc_pre_ms / (double)h->acc_n : 0.0;
   if (step_ms_out) *step_ms_out = h->acc_n ? h->acc_step_ms / (double)h->acc_n : 0.0;
   if (launches_out) *launches_out = h->acc_n;

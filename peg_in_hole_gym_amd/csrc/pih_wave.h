@@ -51,7 +51,7 @@ struct Wave {
     //  stores to be acknowledged) before it stores the flag; this wave reads the mailbox after it has seen the flag.)
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < cepoch) {
       __builtin_amdgcn_s_sleep(4);
-      if (++tries > (1 << 21)) { if (l == 0) atomicExch(cerr, 1); break; }
+      if (++tries > (1 << 21)) { if (l == 0) __hip_atomic_store(cerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // (host-mapped word: the next pih_step fails with -5)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     __syncthreads();

@@ -270,19 +270,17 @@ def _quantiles(first, steps):
     return {"q%02d" % q: int(np.percentile(first, q)) for q in QS} | {"never_share": float((first >= steps).mean()), "min": int(first.min()), "mean": float(first.mean())}
 
 
-def round_state_fp32(B, rel=0.0, rng=None):
+def round_state_fp32(B, rel=0.0, tick=0):
     """fp64 oracle B: pass its state record and warm-start cache through fp32 (what the product's HBM record holds between steps);
-    rel > 0: also perturb the 77 position / velocity words by a relative rel * U(-1, 1)"""
-    s = B.get_state(); c = B.warm_cache()
-    if rel > 0:
-        s[:, :77] *= 1 + rel * rng.uniform(-1, 1, (s.shape[0], 77))
-    B.set_state(f32(s)); B.set_warm_cache(f32(c))
+    rel > 0: also perturb the 77 position / velocity words by a relative rel * U(-1, 1) (in the oracle library: piho_round_state_fp32)"""
+    B.round_state_fp32(rel, 4242, tick)
 
 
-def first_exceedance_run(oracle_mod, product, N, steps=1000, seed=5, action_seed=8, omp=True, yardsticks=("Y1", "Y2", "Y3", "Y4"), tol_pose=1e-3, tol_force=1e-2, progress=None):
+def first_exceedance_run(oracle_mod, product, N, steps=1000, seed=5, action_seed=8, omp=True, yardsticks=("Y1", "Y2", "Y3", "Y4"), tol_pose=1e-3, tol_force=1e-2, progress=None, product_envs=None):
     """-> dict: per-env first-exceedance steps of the product and of every yardstick (pose, force), their quantiles, and the
     maximum tip / obs difference over the env-steps BEFORE the first exceedance.  `product`: GpuProduct or tests/emul's host build,
-    constructed with the same seed, auto_reset as the oracle (library default: off)."""
+    constructed with the same seed, auto_reset as the oracle (library default: off).  product_envs > N: the product steps a LARGER batch
+    (its envs are independent and seeded by index) and its first N envs are compared -- the 4096-env launch checked on 1024 of its envs."""
     A = oracle_mod.Oracle(N, omp=omp, seed=seed)
     Y = {}
     if "Y1" in yardsticks:
@@ -293,10 +291,11 @@ def first_exceedance_run(oracle_mod, product, N, steps=1000, seed=5, action_seed
         Y["Y3"] = oracle_mod.Oracle(N, omp=omp, seed=seed, exit_check_stride=16); round_state_fp32(Y["Y3"])
     if "Y4" in yardsticks:
         Y["Y4"] = oracle_mod.Oracle(N, omp=omp, seed=seed, exit_check_stride=16); round_state_fp32(Y["Y4"])
-    prng = np.random.default_rng(4242)
     # identical seeds: the product's reset state is the oracle's to fp32 rounding (tests: test_reset_matches_oracle)
-    s0 = A.get_state(); sp = product.get_state()
+    M = product_envs or N
+    s0 = A.get_state(); sp = product.get_state()[:N]
     assert np.abs(sp[:, POS] - s0[:, POS]).max() < 1e-6
+    arng = np.random.default_rng(action_seed + 1)          # actions of the product's extra envs (never compared)
     rng = np.random.default_rng(action_seed)
     names = ["product", *Y]
     perr = {k: np.zeros((steps, N)) for k in names}; ferr = {k: np.zeros((steps, N)) for k in names}; oerr = {k: np.zeros((steps, N)) for k in names}
@@ -305,8 +304,8 @@ def first_exceedance_run(oracle_mod, product, N, steps=1000, seed=5, action_seed
     for t in range(steps):
         a = rng.uniform(-1, 1, (N, 4))
         oo, _, do = A.step(a); tipA = A.tip_pose()[:, :3]; fA = A.contact_force()
-        og, _, dg = product.step(a)
-        sg = product.get_state()
+        og, _, dg = product.step(a if M == N else np.concatenate([a, arng.uniform(-1, 1, (M - N, 4))]))
+        sg = product.get_state()[:N]; og = np.asarray(og)[:N]
         perr["product"][t] = np.abs(sg[:, 98:101] - tipA).max(1); ferr["product"][t] = np.abs(sg[:, 105] - fA)
         oerr["product"][t] = np.abs(np.asarray(og) - oo).max(1)
         for k, B in Y.items():
@@ -314,12 +313,12 @@ def first_exceedance_run(oracle_mod, product, N, steps=1000, seed=5, action_seed
             oerr[k][t] = np.abs(ob - oo).max(1)
             perr[k][t] = np.abs(B.tip_pose()[:, :3] - tipA).max(1); ferr[k][t] = np.abs(B.contact_force() - fA)
             if k != "Y1":
-                round_state_fp32(B, 1e-6 if k == "Y4" else 0.0, prng)
+                round_state_fp32(B, 1e-6 if k == "Y4" else 0.0, t + 1)
         ncs[t] = A.ncontacts(); fo[t] = fA; dones |= do.astype(bool)
         if progress and (t + 1) % 100 == 0:
             progress("step %d: product tip err p50 %.2e max %.2e; exceeded so far: %s" % (
                 t + 1, np.median(perr["product"][t]), perr["product"][t].max(), {k: int((perr[k][:t + 1] > tol_pose).any(0).sum()) for k in names}))
-    out = {"N": N, "steps": steps, "seed": seed, "tol_pose_m": tol_pose, "tol_force_N": tol_force, "episodes_ended": int(dones.sum()),
+    out = {"N": N, "product_envs": M, "steps": steps, "seed": seed, "tol_pose_m": tol_pose, "tol_force_N": tol_force, "episodes_ended": int(dones.sum()),
            "mean_contacts": float(ncs.mean()), "max_contacts": int(ncs.max()), "pose": {}, "force": {}, "obs": {}, "first": {}}
     for k in names:
         fp = _first_exceed(perr[k], tol_pose); ff = _first_exceed(ferr[k], tol_force); fb = _first_exceed(oerr[k], tol_pose)
