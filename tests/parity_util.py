@@ -281,6 +281,7 @@ def first_exceedance_run(oracle_mod, product, N, steps=1000, seed=5, action_seed
     maximum tip / obs difference over the env-steps BEFORE the first exceedance.  `product`: GpuProduct or tests/emul's host build,
     constructed with the same seed, auto_reset as the oracle (library default: off).  product_envs > N: the product steps a LARGER batch
     (its envs are independent and seeded by index) and its first N envs are compared -- the 4096-env launch checked on 1024 of its envs."""
+    omp = omp and N >= 64                                  # (a handful of envs: the serial library; thread start-up would dominate)
     A = oracle_mod.Oracle(N, omp=omp, seed=seed)
     Y = {}
     if "Y1" in yardsticks:
