@@ -477,7 +477,7 @@ PIH_HD void controller_targets(real* S, const Params& P, const real* action) { c
 // Controller, part 2 (inside the step kernel): motor rows from the targets in the state record.
 // btMultiBodyJointMotor desired velocity = kp (q* - q)/dt (+ qd - kd qd, kd = 1); default load-time velocity motor
 // (target 0, max impulse 1) on every joint that was never commanded (all 23 pipe joints)
-template <class W> PIH_HD void controller_rows(W& w, Shared& sh, const Params& P) {
+template <class W> PIH_HD void controller_rows(W& w, Shared& sh, const Params& P, int part = 0) {
   real* S = sh.S;
   int posctl_arm = 0; real kp_arm = 0, imp_arm = 1, kp_f = 0, imp_f = 1; int posctl_f = 0;
   if (P.mode == 0) {
@@ -489,11 +489,17 @@ template <class W> PIH_HD void controller_rows(W& w, Shared& sh, const Params& P
     const bool closed = st >= 3 && st < 7;
     posctl_f = 1; kp_f = (real)0.1; imp_f = (closed ? (real)20000 : (real)20) * P.dt;
   }
+  // part 0: all motor rows, before build_rows (which turns word 1 into the row's right-hand side (vt - u) / (J W)).
+  // part 1: only the rows that do not depend on the controller (the 23 pipe motors: target 0, max impulse 1), before build_rows;
+  // part 2: the 9 arm rows AFTER build_rows (called with defer_arm: it left their word 1 alone): the same expression, evaluated once the
+  //         controller's targets are there -- in the fused launch the wait for the controller wavefront then sits behind the response rows.
   w.par(NMOT, [&](int m) {
+    if ((part == 1 && m < 9) || (part == 2 && m >= 9)) return;
     real vt = 0, imp = 1;
     if (m < 7) { if (posctl_arm) { vt = kp_arm * (S[PIH_S_TARGET + m] - S[PIH_S_QARM + m]) / P.dt; imp = imp_arm; } }
     else if (m < 9) { if (posctl_f) { vt = kp_f * (S[PIH_S_TARGET + m] - S[PIH_S_QARM + m]) / P.dt; imp = imp_f; } }
-    sh.mrec[m][1] = vt; sh.mrec[m][3] = imp;
+    sh.mrec[m][1] = part == 2 ? (vt - sh.u[m]) * sh.mrec[m][0] : vt;      // (arm DOF m = motor row m; sh.u is untouched between build_rows and here)
+    sh.mrec[m][3] = imp;
   });
 }
 
@@ -892,7 +898,7 @@ PIH_HD V3 point_vel(const Shared& sh, int L, V3 p) { return ld3(sh.VV[L]) + cros
 // the 23 x 29 pipe block.  On the GPU these stay in registers across the contact-row pass (their LDS words are reused).
 struct MotorW { real w[PIH_OBJ_NJ]; };
 
-template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, const Ovf& ov, MotorW& mw) {
+template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, const Ovf& ov, MotorW& mw, bool defer_arm = false) {
   const real dt = P.dt;
   // link velocities after the free update (contact / motor right-hand sides)
   link_velocities(w, sh);
@@ -935,7 +941,8 @@ template <class W> PIH_HD void build_rows(W& w, Shared& sh, const Params& P, con
       const real di = (real)1 / jw;
       if (ismotor) {
         const int d = link_dof(jm);
-        sh.mrec[g][0] = di; sh.mrec[g][1] = (sh.mrec[g][1] - sh.u[d]) * di; sh.mrec[g][2] = (real)sqrt(P.resid) * di;
+        sh.mrec[g][0] = di; sh.mrec[g][2] = (real)sqrt(P.resid) * di;
+        if (!(defer_arm && g < 9)) sh.mrec[g][1] = (sh.mrec[g][1] - sh.u[d]) * di;      // (deferred arm rows: controller_rows part 2)
         if (g < 9) sh.lrec[g][2] = jw;
       } else {
         real* R = crec_of(sh, ov, c);

@@ -104,11 +104,13 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, const Ovf& ov, int env, 
   w.phase(0);
   if (!frozen) {
     if constexpr (W::controller_inline) controller_targets(S, P, action);     // (host harness; on the GPU the controller runs beside this wave)
-    // The controller's output (joint targets, state-machine words) is first needed by the motor rows -- in action mode not before
-    // build_rows, so the wait for the controller wavefront (fused launch) sits behind collision detection and the articulated-body
-    // sweep; in scripted mode collide() reads the state-machine words (attach / weld), so it sits here.
+    // The controller's output (joint targets, state-machine words) is first needed by the right-hand sides of the nine arm motor rows --
+    // in action mode nothing else reads it, so the wait for the controller wavefront (fused launch) sits behind collision detection,
+    // the articulated-body sweep AND the response rows of build_rows; in scripted mode collide() reads the state-machine words
+    // (attach / weld), so it sits here.
     const bool ctrl_early = P.mode != 0;
     if (ctrl_early) { w.await_controller(sh); controller_rows(w, sh, P); }
+    else controller_rows(w, sh, P, 1);                      // the pipe's motor rows do not depend on the controller
     w.phase(1);
     collide(w, sh, P);
     w.priority(sh.nc);
@@ -129,9 +131,9 @@ PIH_HD void step_env(W& w, Shared& sh, const Params& P, const Ovf& ov, int env, 
         o[5] = sh.c_n[c][0]; o[6] = sh.c_n[c][1]; o[7] = sh.c_n[c][2]; o[8] = sh.c_depth[c]; o[9] = sh.c_mu[c]; o[10] = (real)sh.c_key[c];
       });
     }
-    if (!ctrl_early) { w.await_controller(sh); controller_rows(w, sh, P); }
     MotorW mw;
-    build_rows(w, sh, P, ov, mw);
+    build_rows(w, sh, P, ov, mw, !ctrl_early);
+    if (!ctrl_early) { w.await_controller(sh); controller_rows(w, sh, P, 2); }   // arm motor rows: (target velocity - u) / (J W), now that the targets are there
     w.phase(4);
     int iters = pgs(w, sh, P, ov, mw);
     w.phase(5);

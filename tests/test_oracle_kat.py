@@ -260,3 +260,34 @@ def test_new_seed_needs_a_full_reset_oracle(oracle_mod):
     o.reset(m)
     after = o.get_state()[:, 92]
     assert (after[m == 1] > before[m == 1]).all() and np.array_equal(after[m == 0], before[m == 0])
+
+
+def test_structural_variants_default_is_the_product_algorithm(oracle_mod):
+    """oracle/pih_oracle.h piho_variant (round 4: the structure sweep of tools/ill_conditioned_causes.py): the DEFAULT variant is bit for bit
+    the oracle every parity test uses; each switch changes the rollout; one friction direction leaves the dir-2 multipliers at zero"""
+    N = 16
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, (120, N, 4))
+
+    def roll(**var):
+        o = oracle_mod.Oracle(N, seed=5)
+        if var is not None:
+            o.set_variant(**var)
+        for a in acts:
+            o.step(a)
+        return o
+    base = oracle_mod.Oracle(N, seed=5)
+    for a in acts:
+        base.step(a)
+    sb = base.get_state()
+    np.testing.assert_array_equal(roll().get_state(), sb)                      # explicit defaults == never touched
+    assert base.ncontacts().max() >= 3
+    for var in (dict(row_order=1), dict(friction_dirs=1), dict(mu_clamp=1.0), dict(pipe_motor_impulse=0.0), dict(row_impulse_cap=1e-3), dict(max_coord_vel=5.0)):
+        o = roll(**var)
+        assert not np.array_equal(o.get_state()[:, :77], sb[:, :77]), var
+        assert np.isfinite(o.get_state()).all()
+        if var == dict(friction_dirs=1):
+            lt, _ = o.debug_friction()
+            assert np.abs(lt[:, :, 1]).max() == 0 and np.abs(lt[:, :, 0]).max() > 0
+        if var == dict(max_coord_vel=5.0):
+            assert np.abs(o.get_state()[:, 9:18]).max() <= 5.0 + 1e-12
