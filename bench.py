@@ -330,12 +330,25 @@ def main():
                       "exit_check_stride": int(c.exit_check_stride), "exit_check": "Bullet's cadence (every iteration)" if c.exit_check_stride <= 1 else
                       "sampled: iterations 1..4, 4 + %d k and the last" % c.exit_check_stride, "solver_path": int(c.solver_path)}
     local_obs = torch.zeros(n, odim, device=dev)
-    gathered = torch.empty(world * n, odim, device=dev) if dist is not None and not args.no_allgather else None
+    # The all-gather of the stacked observation (20 B x envs per rank, latency bound) is issued asynchronously and
+    # double-buffered: the gather of step t runs on RCCL's stream beside the kernel of step t + 1 (which does not depend on it), and
+    # the buffers of step t are reused at step t + 2, after that gather has been waited for (a stream wait, not a host wait).
+    gathered = [torch.empty(world * n, odim, device=dev) for _ in range(2)] if dist is not None and not args.no_allgather else None
+    obs_buf = [torch.zeros(n, odim, device=dev) for _ in range(2)]
+    pending = [None, None]
 
     def one_step(t):
-        obs = env.step(actions[t % pool])[0] if env is not None else local_obs
+        k = t & 1
+        if pending[k] is not None:
+            pending[k].wait(); pending[k] = None
+        obs = env.step(actions[t % pool], obs_out=obs_buf[k] if gathered is not None else None)[0] if env is not None else local_obs
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, obs)
+            pending[k] = dist.all_gather_into_tensor(gathered[k], obs, async_op=True)
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait(); pending[k] = None
 
     cword, iword = (44, 32) if fly else (106, 107)
 
@@ -344,6 +357,7 @@ def main():
 
     for t in range(args.preroll + args.warmup):
         one_step(t)
+    drain()
     sync()
     c_start = contacts()
     if env is not None:
@@ -355,6 +369,7 @@ def main():
     t0 = time.perf_counter()
     for t in range(args.steps):
         one_step(args.preroll + args.warmup + t)
+    drain()                                                # the last gathers belong to the timed region
     sync()
     if dist is not None:
         dist.barrier()
@@ -408,7 +423,8 @@ def main():
                            n, "random actions U(-1,1)" if args.mode == "action" else "scripted grasp-and-insert episodes", args.preroll),
                        "task": args.task, "solver": solver_cfg,
                        "envs_per_gpu": n, "total_envs": total_envs, "preroll": args.preroll,
-                       "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + %s all-gather(obs)" % ("RCCL" if args.backend == "nccl" and use_gpu else "gloo"))},
+                       "parallelism": "env-block x%d%s" % (world, "" if gathered is None else " + %s all-gather(obs)" % ("RCCL" if args.backend == "nccl" and use_gpu else "gloo")),
+                       "all_gather": None if gathered is None else "asynchronous, double-buffered: the gather of step t overlaps the kernel of step t + 1"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (alg_bytes * n),
                          "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel",

@@ -77,15 +77,20 @@ class PihVecEnv:
         """uint8-like [n]: envs whose state became non-finite with auto_reset = 0 (re-initialised, done, frozen until reset)."""
         return self.state()[:, self._invalid_word] != 0
 
-    def step(self, actions):
+    def step(self, actions, obs_out=None):
+        """obs_out: optional float32 [n, obs_dim] device tensor to receive the observation instead of self.obs (a caller that hands the
+        observation to an asynchronous consumer -- bench.py's overlapped all-gather -- alternates between two of them)"""
         a = None
         if actions is not None:
             a = actions.to(device=self.device, dtype=torch.float32).contiguous()
             assert a.shape == (self.n, self.action_dim), a.shape
+        obs = self.obs if obs_out is None else obs_out
+        if obs_out is not None:
+            assert obs.shape == self.obs.shape and obs.dtype == torch.float32 and obs.is_contiguous() and obs.device == self.obs.device
         with torch.cuda.device(self.device):
-            self._chk(self.L.pih_step(self.h, a.data_ptr() if a is not None else None, self.obs.data_ptr(), self.reward.data_ptr(),
+            self._chk(self.L.pih_step(self.h, a.data_ptr() if a is not None else None, obs.data_ptr(), self.reward.data_ptr(),
                                       self.done.data_ptr(), self._stream()), "pih_step")
-        return self.obs, self.reward, self.done
+        return obs, self.reward, self.done
 
     def step_n(self, k, actions=None):
         a = None
