@@ -115,31 +115,34 @@ PIH_HD S3 sym_of(const M3& a) { S3 r; r.xx = a.m[0]; r.yy = a.m[4]; r.zz = a.m[8
 // spatial inertia about a reference point: [[A, B], [B^T, C]] acting on (angular; linear) motion vectors
 struct SI { S3 A; M3 B; S3 C; };
 
-// One dt of one env.  S: the env's state record (a per-lane local array); mem: this lane's contact-row scratch.
-// EXTERNAL_IK: the IK targets S[PIH_F_TARGET ..] of THIS step were already computed (pih_fly_pre_kernel: one env per quad of lanes,
-// pih_ikq.h); otherwise the step runs the IK itself, one env per lane (the host harness, and the GPU before round 4).
-template <bool EXTERNAL_IK = false, class Mem>
-PIH_HD void step_env(real* S, const Params& P, int env_global, const real* action, real* obs, real* reward, unsigned char* done, Mem mem, real* dbg) {
+// Where the step takes its IK targets from (ur_execute, envs/utils.py:70-82).  The targets are first needed by the right-hand sides of
+// the six motor rows, i.e. right before the PGS loop -- everything else of the step runs before that.
+struct InlineIk {      // the step runs the IK itself, one env per lane (the host harness; the GPU for batches that fill the chip)
+  PIH_HD void operator()(const real* q, const real* S, const real* action, const Params& P, real* qs) const {
+    Serial sw; real ikT[NJ][12];
+    const Q4 tq = quat_from_euler(action[3], action[4], action[5]);
+    const V3 tp = mk(action[0] - S[PIH_F_OFFSET], action[1] - S[PIH_F_OFFSET + 1], action[2] - S[PIH_F_OFFSET + 2]);
+    ik_chain<Ur5Chain>(sw, ikT, P, q, tp, tq, qs);
+  }
+};
+struct RecordIk {      // the targets were written into the state record before this launch (pih_fly_pre_kernel; measurement switch)
+  PIH_HD void operator()(const real*, const real* S, const real*, const Params&, real* qs) const {
+#pragma unroll
+    for (int i = 0; i < NJ; i++) qs[i] = S[PIH_F_TARGET + i];
+  }
+};
+
+// One dt of one env.  S: the env's state record (a per-lane local array); mem: this lane's contact-row scratch; ctl: one of the above
+// (or the mailbox reader of the fused launch, pih_hip.hip).
+template <class Ctl = InlineIk, class Mem>
+PIH_HD void step_env(real* S, const Params& P, int env_global, const real* action, real* obs, real* reward, unsigned char* done, Mem mem, real* dbg, Ctl ctl = Ctl()) {
   const real dt = P.dt;
   const bool frozen = !P.autoreset && S[PIH_F_DONE] != 0;   // finished envs keep their last values (envs/base_env.py:62,66)
   bool landed = false;
   if (!frozen) {
-    // ---- controller: ur_execute (envs/utils.py:70-82)
     real q[NJ], qd[NJ];
 #pragma unroll
     for (int i = 0; i < NJ; i++) { q[i] = S[PIH_F_Q + i]; qd[i] = S[PIH_F_QD + i]; }
-    real vt[NJ];
-    if constexpr (EXTERNAL_IK) {
-#pragma unroll
-      for (int i = 0; i < NJ; i++) vt[i] = (real)PIH_UR5_KP * (S[PIH_F_TARGET + i] - q[i]) / dt;
-    } else {
-      Serial sw; real ikT[NJ][12]; real qs[NJ];
-      const Q4 tq = quat_from_euler(action[3], action[4], action[5]);
-      const V3 tp = mk(action[0] - S[PIH_F_OFFSET], action[1] - S[PIH_F_OFFSET + 1], action[2] - S[PIH_F_OFFSET + 2]);
-      ik_chain<Ur5Chain>(sw, ikT, P, q, tp, tq, qs);
-#pragma unroll
-      for (int i = 0; i < NJ; i++) { S[PIH_F_TARGET + i] = qs[i]; vt[i] = (real)PIH_UR5_KP * (qs[i] - q[i]) / dt; }
-    }
     // ---- forward kinematics + per-link spatial inertia / bias force about the link origin, world axes
     V3 o[NJ], a[NJ], r[NJ], wv[NJ], ca[NJ], cl[NJ];
     SI I[NJ]; V3 pa[NJ], pl[NJ];        // articulated inertia / bias force (initialised with the link's own)
@@ -301,7 +304,6 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
     for (int j = 0; j < NJ; j++) {
       arm_response(j, -1, mk(0, 0, 0), mk(0, 0, 0), Wm[j]);
       mdi[j] = (real)1 / Wm[j][j];
-      mrhs[j] = (vt[j] - u[j]) * mdi[j];
       const real plo = q[j] - U_LO[j], phi = U_HI[j] - q[j];
       lrl[j] = ((plo > 0 ? -plo / dt : -P.erp * plo / dt) - u[j]) * mdi[j];
       lrh[j] = ((phi > 0 ? -phi / dt : -P.erp * phi / dt) + u[j]) * mdi[j];
@@ -363,6 +365,17 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       } else if (dbg && P.debug) {
         real* d = dbg + 16 + 10 * k;
         for (int t = 0; t < 10; t++) d[t] = 0;
+      }
+    }
+    // ---- controller: ur_execute (envs/utils.py:70-82): IK targets -> POSITION_CONTROL target velocities -> right-hand sides of the motor rows
+    {
+      real qs[NJ];
+      ctl(q, S, action, P, qs);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        S[PIH_F_TARGET + j] = qs[j];
+        const real vt = (real)PIH_UR5_KP * (qs[j] - q[j]) / dt;
+        mrhs[j] = (vt - u[j]) * mdi[j];
       }
     }
     // ---- sequential impulse: per joint (motor, lower limit, upper limit), then the contact normals

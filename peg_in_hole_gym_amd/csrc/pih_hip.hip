@@ -331,12 +331,54 @@ __global__ void __launch_bounds__(256) pih_fly_pre_kernel(Params P, float* __res
   if (j1 < fly::NJ) state[(size_t)(PIH_F_TARGET + j1) * n + env] = q1;
 }
 
-template <bool EXTERNAL_IK>
+// The fused random-fly launch (round 4, as the peg-in-hole one): the first G = ceil(n / 64) blocks are CONTROLLER wavefronts (the IK of 64
+// envs, one per lane, straight into a structure-of-arrays mailbox, then the epoch into the block's flag), the next G blocks the step
+// wavefronts, whose lanes read their targets from the mailbox right before the PGS loop -- after forward kinematics, the articulated-body
+// sweeps, collision detection and all response rows, i.e. later than the 24 us the IK takes.  Every workgroup of the launch carries the
+// step's 120 KB of dynamic LDS, so the layout is used only while 2 G workgroups fit the chip's CUs at once (n <= 8192); bigger batches
+// run the IK inside the step wavefront (MODE 0).  MODE 1: targets from a pre-launch (pih_fly_pre_kernel; measurement switch).
+struct FlyFused { int G, epoch; float* mail; int* flags; int* err; };
+struct MailboxIk {
+  const int* flag; const float* mail; int* err; int epoch, env, n;
+  __device__ __forceinline__ void operator()(const float*, const float*, const float*, const Params&, float* qs) const {
+    int tries = 0;      // (relaxed agent-scope atomics + workgroup fences: see Wave::await_controller)
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < epoch) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++tries > (1 << 21)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int i = 0; i < fly::NJ; i++) qs[i] = __hip_atomic_load(mail + (size_t)i * n + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+template <int MODE>
 __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
                                                              float* __restrict__ obs, float* __restrict__ reward,
-                                                             unsigned char* __restrict__ done, float* __restrict__ dbg, int n) {
+                                                             unsigned char* __restrict__ done, float* __restrict__ dbg, int n, FlyFused F) {
   extern __shared__ float lanemem[];
-  const int env = blockIdx.x * 64 + threadIdx.x;
+  if (MODE == 2 && (int)blockIdx.x < F.G) {
+    // ---- controller role
+    __builtin_amdgcn_s_setprio(3);
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env < n && (P.autoreset || state[(size_t)PIH_F_DONE * n + env] == 0)) {
+      float q[fly::NJ], S3[PIH_F_OFFSET + 3], a[PIH_FLY_ACTION_DIM], qs[fly::NJ];
+#pragma unroll
+      for (int i = 0; i < fly::NJ; i++) q[i] = state[(size_t)(PIH_F_Q + i) * n + env];
+#pragma unroll
+      for (int k = 0; k < 3; k++) S3[PIH_F_OFFSET + k] = state[(size_t)(PIH_F_OFFSET + k) * n + env];
+#pragma unroll
+      for (int k = 0; k < PIH_FLY_ACTION_DIM; k++) a[k] = actions[(size_t)env * PIH_FLY_ACTION_DIM + k];
+      fly::InlineIk()(q, S3, a, P, qs);
+#pragma unroll
+      for (int i = 0; i < fly::NJ; i++) __hip_atomic_store(F.mail + (size_t)i * n + env, qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(F.flags + blockIdx.x, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int blk = MODE == 2 ? blockIdx.x - F.G : blockIdx.x;
+  const int env = blk * 64 + threadIdx.x;
   if (env >= n) return;
   // config.debug = 2: start / end of the wavefront on the chip-wide 100 MHz clock and where it ran (debug words 940 .. 947 of the wave's
   // first env; tools/fly_trace.py) -- never read by the kernel
@@ -353,7 +395,12 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
   }
   float o[PIH_FLY_OBS_DIM], r; unsigned char d;
   fly::LaneMem mem; mem.p = lanemem + threadIdx.x; mem.stride = 64;
-  fly::step_env<EXTERNAL_IK>(S, P, P.env0 + env, a, o, &r, &d, mem, dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr);
+  float* dbge = dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr;
+  if constexpr (MODE == 2) {
+    MailboxIk mb; mb.flag = F.flags + blk; mb.mail = F.mail; mb.err = F.err; mb.epoch = F.epoch; mb.env = env; mb.n = n;
+    fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, mb);
+  } else if constexpr (MODE == 1) fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::RecordIk());
+  else fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::InlineIk());
 #pragma unroll
   for (int w = 0; w < fly::SW; w++) state[(size_t)w * n + env] = S[w];
   if (obs) {
@@ -364,10 +411,10 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
   if (done) done[env] = d;
   if (stamp) {
     const long long ts1 = (long long)__builtin_amdgcn_s_memrealtime();
-    float* o = dbg + (size_t)env * PIH_DEBUG_WORDS;
-    o[940] = (float)(ts0 & 0xFFFF); o[941] = (float)((ts0 >> 16) & 0xFFFF); o[942] = (float)((ts0 >> 32) & 0xFFFF);
-    o[943] = (float)(ts1 & 0xFFFF); o[944] = (float)((ts1 >> 16) & 0xFFFF); o[945] = (float)((ts1 >> 32) & 0xFFFF);
-    o[946] = (float)(__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xFFFF); o[947] = (float)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+    float* o2 = dbg + (size_t)env * PIH_DEBUG_WORDS;
+    o2[940] = (float)(ts0 & 0xFFFF); o2[941] = (float)((ts0 >> 16) & 0xFFFF); o2[942] = (float)((ts0 >> 32) & 0xFFFF);
+    o2[943] = (float)(ts1 & 0xFFFF); o2[944] = (float)((ts1 >> 16) & 0xFFFF); o2[945] = (float)((ts1 >> 32) & 0xFFFF);
+    o2[946] = (float)(__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xFFFF); o2[947] = (float)__builtin_amdgcn_s_getreg((3 << 11) | 20);
   }
 }
 
@@ -552,8 +599,25 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
   if (h->fly) {
     // (dynamic LDS beyond the default 64 KB limit: the per-lane contact rows and candidate staging of 64 envs are LANE_WORDS * 64 words)
     static_assert((size_t)fly::LANE_WORDS * 64 * sizeof(float) <= 160 * 1024, "the random-fly kernel's per-wave LDS exceeds a CU's 160 KB");
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
+    {
+      // fused launch (controller wavefronts + step wavefronts in one grid) while both sets of workgroups -- each with the step's 120 KB of
+      // LDS -- fit the chip's CUs at once; schedule + 8: IK inside the step wavefront, + 16: IK as a quad-per-env pre-launch (switches)
+      int cus = 0; HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+      const int G = (cfg->n_envs + 63) / 64;
+      h->fused = (cfg->schedule & (8 | 16)) == 0 && 2 * G <= cus;
+      if (h->fused) {
+        HIPCHK(h, hipMalloc(&h->mail, (size_t)cfg->n_envs * fly::NJ * sizeof(float)));
+        HIPCHK(h, hipMemset(h->mail, 0, (size_t)cfg->n_envs * fly::NJ * sizeof(float)));
+        HIPCHK(h, hipMalloc(&h->flags, (size_t)G * sizeof(int)));
+        HIPCHK(h, hipMemset(h->flags, 0, (size_t)G * sizeof(int)));
+        HIPCHK(h, hipHostMalloc((void**)&h->errw_host, sizeof(int), hipHostMallocMapped));
+        *h->errw_host = 0;
+        HIPCHK(h, hipHostGetDevicePointer((void**)&h->errw, const_cast<int*>(h->errw_host), 0));
+      }
+    }
     const int nb64 = (cfg->n_envs + 63) / 64;
     hipLaunchKernelGGL(pih_fly_init_offsets_kernel, dim3(nb64), dim3(64), 0, 0, h->state, *offd, cfg->n_envs);
     hipLaunchKernelGGL(pih_fly_reset_kernel, dim3(nb64), dim3(64), 0, 0, h->P, h->state, (const unsigned char*)nullptr, 0, 0, cfg->n_envs);
@@ -657,15 +721,26 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
     t = &h->ev[h->ev_used++];
     HIPCHK(h, hipEventRecord(t->a, s));
   }
-  // measurement switches.  peg-in-hole two-launch path: +8 = controller one env per lane, +16 = one env per quad.  random-fly: the
-  // default is the IK inside the one-env-per-lane step kernel; +16 = the quad-per-env pre-kernel (measured slower: tools/ik_bench.py)
-  const bool lane_ctrl = h->fly ? (h->cfg.schedule & 16) == 0 : (h->cfg.schedule & 8) != 0;
-  if (h->fly) {   // controller (one env per quad of lanes), then physics (one env per lane)
-    const dim3 grid((h->cfg.n_envs + 63) / 64); const size_t lds = (size_t)fly::LANE_WORDS * 64 * sizeof(float);
-    if (!lane_ctrl) hipLaunchKernelGGL(pih_fly_pre_kernel, grid, dim3(256), 0, s, h->P, h->state, actions, h->cfg.n_envs);
-    if (t) HIPCHK(h, hipEventRecord(t->b, s));
-    if (lane_ctrl) hipLaunchKernelGGL(pih_fly_step_kernel<false>, grid, dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs);
-    else hipLaunchKernelGGL(pih_fly_step_kernel<true>, grid, dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs);
+  // measurement switches.  peg-in-hole two-launch path: + 8 = controller one env per lane, + 16 = one env per quad.  random-fly: default =
+  // the fused launch (IK in controller wavefronts of the same grid; batches beyond 8192 envs: IK inside the step wavefront), + 8 = IK
+  // inside the step wavefront, + 16 = the quad-per-env pre-launch
+  const bool lane_ctrl = (h->cfg.schedule & 8) != 0;
+  if (h->fly) {
+    const int G = (h->cfg.n_envs + 63) / 64; const size_t lds = (size_t)fly::LANE_WORDS * 64 * sizeof(float);
+    FlyFused FF; memset(&FF, 0, sizeof FF);
+    if (h->fused) {
+      if (*h->errw_host) { h->err = CTRL_TIMEOUT_MSG; return -5; }
+      FF.G = G; FF.epoch = ++h->epoch; FF.mail = h->mail; FF.flags = h->flags; FF.err = h->errw;
+      if (t) HIPCHK(h, hipEventRecord(t->b, s));
+      hipLaunchKernelGGL(pih_fly_step_kernel<2>, dim3(2 * G), dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
+    } else if (h->cfg.schedule & 16) {
+      hipLaunchKernelGGL(pih_fly_pre_kernel, dim3(G), dim3(256), 0, s, h->P, h->state, actions, h->cfg.n_envs);
+      if (t) HIPCHK(h, hipEventRecord(t->b, s));
+      hipLaunchKernelGGL(pih_fly_step_kernel<1>, dim3(G), dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
+    } else {
+      if (t) HIPCHK(h, hipEventRecord(t->b, s));
+      hipLaunchKernelGGL(pih_fly_step_kernel<0>, dim3(G), dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
+    }
     if (t) HIPCHK(h, hipEventRecord(t->c, s));
     HIPCHK(h, hipGetLastError());
     return 0;

@@ -178,3 +178,22 @@ def test_fly_facade_readme_usage_on_gpu(torch_mod):
     ob, r, d, inf = t.get_info()
     assert ob.shape == (6,) and np.isfinite(ob).all()
     t.close()
+
+
+def test_fused_fly_launch_equals_ik_inside_the_step_wavefront():
+    """Round 4: the random-fly step as ONE launch with the IK in controller wavefronts (mailbox + flag, targets read right before the PGS
+    loop) against the IK inside the step wavefront (pih_config.schedule + 8: the same per-lane code) -- bit-identical states, observations,
+    rewards and dones across auto-resets; 4 096 envs (fused) and 10 000 envs (beyond 8 192 the library keeps the IK inside)."""
+    import torch
+    from peg_in_hole_gym_amd.vec_env import PihVecEnv
+    for n in (4096, 10000):
+        kw = dict(task_id=1, seed=3, dt=DT, auto_reset=1, max_episode_steps=60, contact_margin=0.02)
+        a = PihVecEnv(n, **kw); b = PihVecEnv(n, schedule=1 + 8, **kw)
+        gen = torch.Generator(device="cuda").manual_seed(9)
+        for t in range(130):
+            act = torch.rand(n, 6, device="cuda", generator=gen) * 2 - 1
+            oa = [x.clone() for x in a.step(act)]; ob = b.step(act)
+            for x, y in zip(oa, ob):
+                assert torch.equal(x, y), "n %d step %d" % (n, t)
+        assert torch.equal(a.state(), b.state())
+        a.set_timing(1); a.step(act); a.timing2()          # (-5 if a step wavefront ever timed out waiting for its controller wavefront)

@@ -52,4 +52,5 @@ if __name__ == "__main__":
     for task, name in ((0, "peg-in-hole"), (1, "random-fly")):
         for n in (1024, 4096, 16384):
             f = time_pre(n, 1, task); q = time_pre(n, 1 + 16, task); l = time_pre(n, 1 + 8, task)
-            print("%s n=%5d: default (peg-in-hole: ONE fused launch) %.1f + %.1f us; two launches, controller one env per QUAD %.1f + %.1f us; one env per LANE %.1f + %.1f us" % (name, n, f[0], f[1], q[0], q[1], l[0], l[1]))
+            print("%s n=%5d: default (ONE fused launch%s) %.1f + %.1f us; controller / IK as a pre-launch, one env per QUAD %.1f + %.1f us; %s %.1f + %.1f us" % (
+                name, n, "; random-fly beyond 8192 envs: IK inside the step wavefront" if task else "", f[0], f[1], q[0], q[1], "IK inside the step wavefront" if task else "pre-launch, one env per LANE", l[0], l[1]))
