@@ -428,7 +428,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (alg_bytes * n),
                          "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel",
-                         "launches_per_step": ("one: pih_fly_step_kernel, IK inside" if not (args.schedule & 16) else "two: pih_fly_pre_kernel (IK, one env per quad of lanes) + pih_fly_step_kernel") if fly else
+                         "launches_per_step": ("two: pih_fly_pre_kernel (IK, one env per quad of lanes) + pih_fly_step_kernel" if (args.schedule & 16) else
+                                               "one: pih_fly_step_kernel, IK inside the step wavefront" if (args.schedule & 8) or n > 8192 else
+                                               "one: pih_fly_step_kernel = IK controller wavefronts + step wavefronts (fused launch)") if fly else
                                               ("two: pih_pre_kernel (controller) + pih_step_kernel" if (args.schedule & 24) or (args.schedule & 3) == 2 else
                                                "one: pih_step_kernel = controller wavefronts + env wavefronts (fused launch); pre_kernel_avg_ms is the gap between two launches"),
                          "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches, "event_stride": args.timing_stride,

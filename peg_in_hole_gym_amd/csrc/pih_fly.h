@@ -132,6 +132,19 @@ struct RecordIk {      // the targets were written into the state record before 
   }
 };
 
+// Diagnostic phase stamps (config.debug = 2, GPU only): shader-clock cycles since the previous stamp into debug word 900 + k of the env
+// (tools/fly_trace.py): 0 kinematics + inertias + collision candidates, 1 articulated-body sweeps, 2 motor response rows, 3 contact rows,
+// 4 wait for / computation of the IK targets, 5 PGS, 6 integration + outputs.
+#ifndef PIH_PLATFORM_DEFINED
+struct FlyStamp {
+  real* dbg; long long t;
+  PIH_HD FlyStamp(real* d, bool on) : dbg(on ? d : nullptr), t(0) { if (dbg) t = (long long)__builtin_readcyclecounter(); }
+  PIH_HD void operator()(int k) { if (dbg) { const long long n = (long long)__builtin_readcyclecounter(); dbg[900 + k] = (real)(n - t); t = n; } }
+};
+#else
+struct FlyStamp { FlyStamp(real*, bool) {} void operator()(int) {} };
+#endif
+
 // One dt of one env.  S: the env's state record (a per-lane local array); mem: this lane's contact-row scratch; ctl: one of the above
 // (or the mailbox reader of the fused launch, pih_hip.hip).
 template <class Ctl = InlineIk, class Mem>
@@ -139,6 +152,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
   const real dt = P.dt;
   const bool frozen = !P.autoreset && S[PIH_F_DONE] != 0;   // finished envs keep their last values (envs/base_env.py:62,66)
   bool landed = false;
+  FlyStamp stamp(dbg, dbg && P.debug == 2);
   if (!frozen) {
     real q[NJ], qd[NJ];
 #pragma unroll
@@ -216,6 +230,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         }
       }
     }
+    stamp(0);
     // ---- ABA inward sweep: U = I^A S, D, u; hand (I^a, p^a) up to the parent's origin
     V3 Ua[NJ], Ul[NJ]; real Dinv[NJ], uu[NJ];
 #pragma unroll
@@ -277,6 +292,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
 #pragma unroll
       for (int i = 0; i < FND; i++) dbg[i] = udot[i];
     }
+    stamp(1);
     // ---- unit-impulse responses of the arm from the articulated quantities: generalized impulse g (per joint) plus a linear
     // impulse `f` at point `p` on link `la` (la < 0: none) -> joint velocity changes w[0..5]
     auto arm_response = [&](int jm, int la, V3 p, V3 f, real* w) {
@@ -308,6 +324,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       lrl[j] = ((plo > 0 ? -plo / dt : -P.erp * plo / dt) - u[j]) * mdi[j];
       lrh[j] = ((phi > 0 ? -phi / dt : -P.erp * phi / dt) + u[j]) * mdi[j];
     }
+    stamp(2);
     // contact candidates of all NC slots -> lane memory (slot i: sphere i vs arm; slot NS + i: sphere i vs table; slot 2 NS + a: arm link
     // 1 + a vs the table): word 0 = link + 2 (0 = slot empty, 1 = no arm link), 1-3 n, 4-6 p, 7 depth.  Staged so that the row build below is
     // ONE rolled loop: as 15 inlined copies (each with its own impulse-response sweep) it was a third of the kernel's 75 KB of code, which
@@ -367,6 +384,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         for (int t = 0; t < 10; t++) d[t] = 0;
       }
     }
+    stamp(3);
     // ---- controller: ur_execute (envs/utils.py:70-82): IK targets -> POSITION_CONTROL target velocities -> right-hand sides of the motor rows
     {
       real qs[NJ];
@@ -378,6 +396,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         mrhs[j] = (vt - u[j]) * mdi[j];
       }
     }
+    stamp(4);
     // ---- sequential impulse: per joint (motor, lower limit, upper limit), then the contact normals
     real du[FND];
 #pragma unroll
@@ -431,6 +450,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       dbg[12] = (real)nc; dbg[13] = (real)it;
       for (int c = 0; c < nc; c++) dbg[200 + c] = mem.at(c * CW + 23);    // lambda_n of compacted contact c (contact records occupy words 16 .. 16 + 10 NC)
     }
+    stamp(5);
     // ---- integrate
 #pragma unroll
     for (int i = 0; i < FND; i++) u[i] = clampr(u[i] + du[i], -PIH_MAX_COORD_VEL, PIH_MAX_COORD_VEL);
@@ -474,6 +494,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
     fly::reset_state(S, P, env_global);
     if (bad && !P.autoreset) { S[PIH_F_DONE] = 1; S[PIH_F_INVALID] = 1; }
   }
+  stamp(6);
 }
 
 }  // namespace fly

@@ -27,4 +27,13 @@ for rep in range(3):
     print("launch %d: %d wavefronts; HIP events around the call %.1f us; first wave start .. last wave end %.1f us; wave durations mean %.1f min %.1f max %.1f us; starts within %.1f us; "
           "distinct (xcc, se, cu, simd) %d, distinct CUs %d, XCDs %d" % (rep, len(s), e0.elapsed_time(e1) * 1e3, float(e.max()), float((e - s).mean()), float((e - s).min()), float((e - s).max()), float(s.max()),
                                                                         len(set(zip(xcc.tolist(), se.tolist(), cu.tolist(), simd.tolist()))), len(set(zip(xcc.tolist(), se.tolist(), cu.tolist()))), len(set(xcc.tolist()))))
-    mean_it = env.state()[:, 32].mean().item()
+    # phase stamps (shader-clock cycles, all lanes of a wave carry the wave's values): per wave, then mean / max over the waves
+    ph = env.debug().double().cpu()[::64, 900:907]
+    names = ["kinematics+collision", "ABA sweeps", "motor responses", "contact rows", "IK targets (wait)", "PGS", "integrate+outputs"]
+    slow = int((e - s).argmax())
+    print("   phases, k cycles mean over waves / slowest wave: " + "; ".join("%s %.1f / %.1f" % (nm, ph[:, i].mean() / 1e3, ph[slow, i] / 1e3) for i, nm in enumerate(names)) +
+          "; sum %.1f / %.1f" % (ph.sum(1).mean() / 1e3, ph[slow].sum() / 1e3))
+    dbg = env.debug().double().cpu()
+    nc = dbg[:, 12].reshape(-1, 64); it = dbg[:, 13].reshape(-1, 64)
+    print("   per wave: max contacts over lanes mean %.1f max %d; max PGS iterations over lanes mean %.1f max %d; slowest wave: max contacts %d, max iterations %d" % (
+        nc.max(1).values.mean(), int(nc.max()), it.max(1).values.mean(), int(it.max()), int(nc[slow].max()), int(it[slow].max())))
