@@ -132,6 +132,16 @@ struct RecordIk {      // the targets were written into the state record before 
   }
 };
 
+// "these 24 values are in registers NOW": an empty asm that takes them as read-write register operands, so that the loads that produce
+// them are all issued, and waited for once, before it (GPU); nothing on the host
+#ifndef PIH_PLATFORM_DEFINED
+#define PIH_FLY_PIN24(R) __asm__ volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]), "+v"(R[8]), "+v"(R[9]), "+v"(R[10]), "+v"(R[11]), \
+                                              "+v"(R[12]), "+v"(R[13]), "+v"(R[14]), "+v"(R[15]), "+v"(R[16]), "+v"(R[17]), "+v"(R[18]), "+v"(R[19]), "+v"(R[20]), "+v"(R[21]), "+v"(R[22]), "+v"(R[23]))
+#else
+#define PIH_FLY_PIN24(R) ((void)0)
+#endif
+static_assert(CW == 24, "PIH_FLY_PIN24 names the 24 words of a contact record");
+
 // Diagnostic phase stamps (config.debug = 2, GPU only): shader-clock cycles since the previous stamp into debug word 900 + k of the env
 // (tools/fly_trace.py): 0 kinematics + inertias + collision candidates, 1 articulated-body sweeps, 2 motor response rows, 3 contact rows,
 // 4 wait for / computation of the IK targets, 5 PGS, 6 integration + outputs.
@@ -425,21 +435,28 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         for (int k = 0; k < NJ; k++) du[k] += Wm[j][k] * tot;
       }
       for (int c = 0; c < nc; c++) {
+        // the whole 24-word record of the contact is read in ONE batch and pinned in registers before any of it is used: left to the
+        // compiler (at the register limit) the loop read two words, waited, used them, read the next two -- twelve LDS round trips per
+        // contact, 4 - 6 k cycles per PGS iteration for a wave whose lanes have up to six contacts (profiles/r04_fly_trace.txt)
         const int b = c * CW;
+        real R[CW];
+#pragma unroll
+        for (int i = 0; i < CW; i++) R[i] = mem.at(b + i);
+        PIH_FLY_PIN24(R);
         real jd = 0;
 #pragma unroll
-        for (int L = 0; L < NJ; L++) jd += mem.at(b + L) * du[L];
-        const V3 n = mk(mem.at(b + 12), mem.at(b + 13), mem.at(b + 14)), rxn = mk(mem.at(b + 15), mem.at(b + 16), mem.at(b + 17));
+        for (int L = 0; L < NJ; L++) jd += R[L] * du[L];
+        const V3 n = mk(R[12], R[13], R[14]), rxn = mk(R[15], R[16], R[17]);
         jd += dot(n, mk(du[6], du[7], du[8])) + dot(rxn, mk(du[9], du[10], du[11]));
-        const real di = mem.at(b + 21), lam = mem.at(b + 23);
-        real dl = mem.at(b + 22) - jd * di;
+        const real di = R[21], lam = R[23];
+        real dl = R[22] - jd * di;
         const real sum = max_(lam + dl, (real)0);
         dl = sum - lam; mem.at(b + 23) = sum;
 #pragma unroll
-        for (int L = 0; L < NJ; L++) du[L] += mem.at(b + 6 + L) * dl;
+        for (int L = 0; L < NJ; L++) du[L] += R[6 + L] * dl;
         const real im = dl * omass_inv;
         du[6] += n.x * im; du[7] += n.y * im; du[8] += n.z * im;
-        du[9] += mem.at(b + 18) * dl; du[10] += mem.at(b + 19) * dl; du[11] += mem.at(b + 20) * dl;
+        du[9] += R[18] * dl; du[10] += R[19] * dl; du[11] += R[20] * dl;
         { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
       }
       if (worst <= 0) { it++; break; }
