@@ -434,14 +434,17 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
 #pragma unroll
         for (int k = 0; k < NJ; k++) du[k] += Wm[j][k] * tot;
       }
-      for (int c = 0; c < nc; c++) {
-        // the whole 24-word record of the contact is read in ONE batch and pinned in registers before any of it is used: left to the
-        // compiler (at the register limit) the loop read two words, waited, used them, read the next two -- twelve LDS round trips per
-        // contact, 4 - 6 k cycles per PGS iteration for a wave whose lanes have up to six contacts (profiles/r04_fly_trace.txt)
-        const int b = c * CW;
-        real R[CW];
+      // Contact rows.  The whole 24-word record of a contact is read in ONE batch and pinned in registers before any of it is used: left
+      // to the compiler (at the register limit) the loop read two words, waited, used them, read the next two -- twelve LDS round trips
+      // per contact, 4 - 6 k cycles per PGS iteration for a wave whose lanes have up to six contacts (profiles/r04_fly_trace.txt).  And
+      // the record of contact c + 1 is requested before contact c is worked on (two register sets, the loop advances by two contacts):
+      // the round trip of a record hides behind the arithmetic of the previous one.  (A lane reads up to two records past its own
+      // last contact: inside its row area or the candidate words behind it, never used.)
+      auto load_rec = [&](real* R, int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < CW; i++) R[i] = mem.at(b + i);
+        for (int i = 0; i < CW; i++) R[i] = mem.at(c * CW + i);
+      };
+      auto solve_rec = [&](real* R, int c) __attribute__((always_inline)) {
         PIH_FLY_PIN24(R);
         real jd = 0;
 #pragma unroll
@@ -451,13 +454,24 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         const real di = R[21], lam = R[23];
         real dl = R[22] - jd * di;
         const real sum = max_(lam + dl, (real)0);
-        dl = sum - lam; mem.at(b + 23) = sum;
+        dl = sum - lam; mem.at(c * CW + 23) = sum;
 #pragma unroll
         for (int L = 0; L < NJ; L++) du[L] += R[6 + L] * dl;
         const real im = dl * omass_inv;
         du[6] += n.x * im; du[7] += n.y * im; du[8] += n.z * im;
         du[9] += R[18] * dl; du[10] += R[19] * dl; du[11] += R[20] * dl;
         { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
+      };
+      static_assert((NC + 2) * CW <= LANE_WORDS, "the read-ahead of up to two records stays inside the lane's words");
+      if (nc > 0) {
+        real Ra[CW], Rb[CW];
+        load_rec(Ra, 0);
+        for (int c = 0; c < nc; c += 2) {
+          load_rec(Rb, c + 1);
+          solve_rec(Ra, c);
+          load_rec(Ra, c + 2);
+          if (c + 1 < nc) solve_rec(Rb, c + 1);
+        }
       }
       if (worst <= 0) { it++; break; }
     }
