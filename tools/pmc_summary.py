@@ -22,18 +22,16 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     out[c.lower() + "_kib"] = sum(vals) / len(vals) if vals else None
     out[c.lower() + "_launches"] = len(vals)
     out["n_envs"] = grid // lanes_per_env if grid else None
-    if out["n_envs"] and not fly:
-        # the fused launch (round 4) has ceil(n / 64) controller wavefronts in front of the n env wavefronts: blocks = n + ceil(n / 64)
-        blocks = out["n_envs"]; n = blocks
-        while n > 0 and n + (n + 63) // 64 > blocks:
-            n -= 1
+    if out["n_envs"]:
+        # the fused launches (round 4) carry controller wavefronts: peg-in-hole blocks = n + ceil(n / 64) (one wavefront per env), random-fly
+        # lanes = 2 x 64 ceil(n / 64) (one lane per env); the bench line of the same pass names the batch
         try:
             bj = json.loads(open(os.path.join(root, "gpurun_out", "pmc_%s%s_%s.bench.json" % (tag, suf, c))).read().strip().splitlines()[-1])
-            if bj["config"]["envs_per_gpu"] in (n, blocks):
-                n = bj["config"]["envs_per_gpu"]
+            n = int(bj["config"]["envs_per_gpu"]); g = (n + 63) // 64
+            if out["n_envs"] in (n, n + g, 2 * 64 * g, 64 * g):
+                out["launch_units"] = out["n_envs"]; out["n_envs"] = n
         except Exception:  # noqa: BLE001
             pass
-        out["n_envs"] = n; out["blocks"] = blocks
 if out.get("fetch_size_kib") is not None and out.get("write_size_kib") is not None:
     out["traffic_raw"] = (out["fetch_size_kib"] + out["write_size_kib"]) * 1024
     out["traffic_fetch_x2"] = (2 * out["fetch_size_kib"] + out["write_size_kib"]) * 1024
