@@ -112,7 +112,7 @@ typedef struct pih_config {
   int32_t exit_check_stride;  /* cadence of the PGS early-exit test (Bullet: largest squared row residual <= residual_threshold, evaluated after
                                  EVERY iteration).  1 = Bullet's cadence; s > 1 = the test runs in iterations 1..4, then in iterations 4 + s k and in
                                  the last one (an env that meets the threshold between two tests runs at most s - 1 further iterations, each of
-                                 whose row updates is below the threshold).  Default 16; the oracle has the same switch, tests/test_gpu_defaults.py
+                                 whose row updates is below the threshold).  Both tasks.  Default 16; the oracle has the same switch, tests/test_gpu_defaults.py
                                  bounds the difference against Bullet's cadence; bench.py reports the value it ran with */
   int32_t object_id;          /* random-fly: which free-flying object (index into PIH_FLY_OBJ_NAMES of include/pih_model.h, generated from the
                                  reference's asset files; args[0] of README.md:38): 0 'Banana', 1 'Amicelli' */

@@ -332,7 +332,7 @@ static void fly_step_env(piho_fly_handle* h, int e, const real* action, real* ob
       for (int k = 0; k < FND; k++) dv[k] += r->W[k] * dl;
       real rs = dl / r->dinv; if (rs * rs > res2) res2 = rs * rs;
     }
-    if (res2 <= c->residual_threshold) break;
+    if (exit_checked(it + 1, c->solver_iters, c->exit_check_stride) && res2 <= c->residual_threshold) break;   /* cadence: 1 = Bullet's (every iteration); s > 1 = the product's */
   }
   for (int i = 0; i < FND; i++) u[i] = clampd(u[i] + dv[i], -MAX_COORD_VEL, MAX_COORD_VEL);
   E->contact_force = 0;

@@ -18,6 +18,7 @@
 // responses from the same articulated inertias; sequential-impulse PGS over (motor, lower limit, upper limit) per joint, then
 // the contact normals.  The oracle derives the same physics by RNEA + dense Cholesky.
 #pragma once
+#include <type_traits>
 #include "pih_common.h"
 
 namespace pih {
@@ -414,66 +415,77 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
     real lam_m[NJ], lam_lo[NJ], lam_hi[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) { lam_m[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
+    // One sweep over the rows; CHECK: also Bullet's exit test -- the largest squared row residual against residual_threshold.  The test
+    // runs at the cadence of pih_config.exit_check_stride, as in the peg-in-hole solvers (include/pih.h): 1 = after every iteration
+    // (Bullet); s > 1 = iterations 1 .. 4, 4 + s k and the last one (default 16).  Every wavefront runs to the iteration count of its
+    // slowest lane anyway (49 - 50 of 50 with 64 envs per wave), so the 42 instructions the test costs per sweep bought nothing.
+    auto sweep = [&](auto CHECKTAG) __attribute__((always_inline)) -> real {
+      constexpr bool CHECK = decltype(CHECKTAG)::value;
+      real worst = -1;
+  #pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const real lim = U_EFFORT[j] * dt, di = mdi[j];
+          real dl = mrhs[j] - du[j] * di, sum = med3_(lam_m[j] + dl, -lim, lim);
+          dl = sum - lam_m[j]; lam_m[j] = sum;
+          real tot = dl;
+          if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
+          real dj = du[j] + dl * Wm[j][j];
+          real d2 = lrl[j] - dj * di, s2 = max_(lam_lo[j] + d2, (real)0);
+          d2 = s2 - lam_lo[j]; lam_lo[j] = s2; tot += d2; dj += d2 * Wm[j][j];
+          if (CHECK) { const real v = d2 * d2 - P.resid * di * di; worst = v > worst ? v : worst; }
+          real d3 = lrh[j] + dj * di, s3 = max_(lam_hi[j] + d3, (real)0);
+          d3 = s3 - lam_hi[j]; lam_hi[j] = s3; tot -= d3;
+          if (CHECK) { const real v = d3 * d3 - P.resid * di * di; worst = v > worst ? v : worst; }
+  #pragma unroll
+          for (int k = 0; k < NJ; k++) du[k] += Wm[j][k] * tot;
+        }
+        // Contact rows.  The whole 24-word record of a contact is read in ONE batch and pinned in registers before any of it is used: left
+        // to the compiler (at the register limit) the loop read two words, waited, used them, read the next two -- twelve LDS round trips
+        // per contact, 4 - 6 k cycles per PGS iteration for a wave whose lanes have up to six contacts (profiles/r04_fly_trace.txt).  And
+        // the record of contact c + 1 is requested before contact c is worked on (two register sets, the loop advances by two contacts):
+        // the round trip of a record hides behind the arithmetic of the previous one.  (A lane reads up to two records past its own
+        // last contact: inside its row area or the candidate words behind it, never used.)
+        auto load_rec = [&](real* R, int c) __attribute__((always_inline)) {
+  #pragma unroll
+          for (int i = 0; i < CW; i++) R[i] = mem.at(c * CW + i);
+        };
+        auto solve_rec = [&](real* R, int c) __attribute__((always_inline)) {
+          PIH_FLY_PIN24(R);
+          real jd = 0;
+  #pragma unroll
+          for (int L = 0; L < NJ; L++) jd += R[L] * du[L];
+          const V3 n = mk(R[12], R[13], R[14]), rxn = mk(R[15], R[16], R[17]);
+          jd += dot(n, mk(du[6], du[7], du[8])) + dot(rxn, mk(du[9], du[10], du[11]));
+          const real di = R[21], lam = R[23];
+          real dl = R[22] - jd * di;
+          const real sum = max_(lam + dl, (real)0);
+          dl = sum - lam; mem.at(c * CW + 23) = sum;
+  #pragma unroll
+          for (int L = 0; L < NJ; L++) du[L] += R[6 + L] * dl;
+          const real im = dl * omass_inv;
+          du[6] += n.x * im; du[7] += n.y * im; du[8] += n.z * im;
+          du[9] += R[18] * dl; du[10] += R[19] * dl; du[11] += R[20] * dl;
+          if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
+        };
+        static_assert((NC + 2) * CW <= LANE_WORDS, "the read-ahead of up to two records stays inside the lane's words");
+        if (nc > 0) {
+          real Ra[CW], Rb[CW];
+          load_rec(Ra, 0);
+          for (int c = 0; c < nc; c += 2) {
+            load_rec(Rb, c + 1);
+            solve_rec(Ra, c);
+            load_rec(Ra, c + 2);
+            if (c + 1 < nc) solve_rec(Rb, c + 1);
+          }
+        }
+      return worst;
+    };
     int it = 0;
     for (; it < P.iters; it++) {
-      real worst = -1;
-#pragma unroll
-      for (int j = 0; j < NJ; j++) {
-        const real lim = U_EFFORT[j] * dt, di = mdi[j];
-        real dl = mrhs[j] - du[j] * di, sum = med3_(lam_m[j] + dl, -lim, lim);
-        dl = sum - lam_m[j]; lam_m[j] = sum;
-        real tot = dl;
-        { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
-        real dj = du[j] + dl * Wm[j][j];
-        real d2 = lrl[j] - dj * di, s2 = max_(lam_lo[j] + d2, (real)0);
-        d2 = s2 - lam_lo[j]; lam_lo[j] = s2; tot += d2; dj += d2 * Wm[j][j];
-        { const real v = d2 * d2 - P.resid * di * di; worst = v > worst ? v : worst; }
-        real d3 = lrh[j] + dj * di, s3 = max_(lam_hi[j] + d3, (real)0);
-        d3 = s3 - lam_hi[j]; lam_hi[j] = s3; tot -= d3;
-        { const real v = d3 * d3 - P.resid * di * di; worst = v > worst ? v : worst; }
-#pragma unroll
-        for (int k = 0; k < NJ; k++) du[k] += Wm[j][k] * tot;
-      }
-      // Contact rows.  The whole 24-word record of a contact is read in ONE batch and pinned in registers before any of it is used: left
-      // to the compiler (at the register limit) the loop read two words, waited, used them, read the next two -- twelve LDS round trips
-      // per contact, 4 - 6 k cycles per PGS iteration for a wave whose lanes have up to six contacts (profiles/r04_fly_trace.txt).  And
-      // the record of contact c + 1 is requested before contact c is worked on (two register sets, the loop advances by two contacts):
-      // the round trip of a record hides behind the arithmetic of the previous one.  (A lane reads up to two records past its own
-      // last contact: inside its row area or the candidate words behind it, never used.)
-      auto load_rec = [&](real* R, int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < CW; i++) R[i] = mem.at(c * CW + i);
-      };
-      auto solve_rec = [&](real* R, int c) __attribute__((always_inline)) {
-        PIH_FLY_PIN24(R);
-        real jd = 0;
-#pragma unroll
-        for (int L = 0; L < NJ; L++) jd += R[L] * du[L];
-        const V3 n = mk(R[12], R[13], R[14]), rxn = mk(R[15], R[16], R[17]);
-        jd += dot(n, mk(du[6], du[7], du[8])) + dot(rxn, mk(du[9], du[10], du[11]));
-        const real di = R[21], lam = R[23];
-        real dl = R[22] - jd * di;
-        const real sum = max_(lam + dl, (real)0);
-        dl = sum - lam; mem.at(c * CW + 23) = sum;
-#pragma unroll
-        for (int L = 0; L < NJ; L++) du[L] += R[6 + L] * dl;
-        const real im = dl * omass_inv;
-        du[6] += n.x * im; du[7] += n.y * im; du[8] += n.z * im;
-        du[9] += R[18] * dl; du[10] += R[19] * dl; du[11] += R[20] * dl;
-        { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
-      };
-      static_assert((NC + 2) * CW <= LANE_WORDS, "the read-ahead of up to two records stays inside the lane's words");
-      if (nc > 0) {
-        real Ra[CW], Rb[CW];
-        load_rec(Ra, 0);
-        for (int c = 0; c < nc; c += 2) {
-          load_rec(Rb, c + 1);
-          solve_rec(Ra, c);
-          load_rec(Ra, c + 2);
-          if (c + 1 < nc) solve_rec(Rb, c + 1);
-        }
-      }
-      if (worst <= 0) { it++; break; }
+      const int i1 = it + 1;
+      const bool chk = P.checkstride <= 1 || i1 <= 4 || i1 == P.iters || (i1 - 4) % P.checkstride == 0;
+      if (chk) { if (sweep(std::true_type{}) <= 0) { it++; break; } }
+      else sweep(std::false_type{});
     }
     real cf = 0;
     for (int c = 0; c < nc; c++) cf += mem.at(c * CW + 23);

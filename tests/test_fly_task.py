@@ -279,3 +279,26 @@ def test_task_registry_and_facade_for_random_fly():
     t.apply_action(np.zeros(6, dtype=np.float32))
     ob, r, d, inf = t.get_info()
     assert ob.shape == (6,) and r in (0.0, 1.0) and isinstance(d, bool) and inf == {}
+
+
+def test_fly_exit_cadence_host_build_matches_same_cadence_oracle(oracle_mod):
+    """the sampled exit-test cadence of the random-fly PGS (pih_config.exit_check_stride, default 16) on the fp64 host build: iteration
+    counts identical to the oracle run at the same cadence, state equal to rounding; against Bullet's cadence 0 .. 16 more iterations"""
+    O = oracle_mod
+    n = 32
+    kw = dict(seed=5, dt=DT, auto_reset=1, max_episode_steps=120)
+    A = O.FlyOracle(n, **kw); B = O.FlyOracle(n, exit_check_stride=16, **kw)
+    e = E.EmulFly(n, "f64", debug=1, exit_check_stride=16, **kw)
+    rng = np.random.default_rng(2)
+    dA = []; early = 0
+    for t in range(200):
+        a = rng.uniform(-1, 1, (n, 6))
+        s = B.get_state(); A.set_state(s); e.set_state(s)
+        A.step(a); _, _, dn = B.step(a); e.step(a)
+        it = e.get_debug()[:, 13].astype(int)
+        live = dn == 0
+        np.testing.assert_array_equal(it[live], B.pgs_iters()[live])
+        assert np.abs(e.get_state()[live][:, :31] - B.get_state()[live][:, :31]).max() < 5e-8      # (the fp64 bound of the one-step test above)
+        dA.append((it - A.pgs_iters())[live]); early += int((B.pgs_iters()[live] < 50).sum())
+    dA = np.concatenate(dA)
+    assert early > 500 and dA.min() >= 0 and dA.max() <= 46 and (dA > 0).any()

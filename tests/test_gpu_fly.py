@@ -197,3 +197,41 @@ def test_fused_fly_launch_equals_ik_inside_the_step_wavefront():
                 assert torch.equal(x, y), "n %d step %d" % (n, t)
         assert torch.equal(a.state(), b.state())
         a.set_timing(1); a.step(act); a.timing2()          # (-5 if a step wavefront ever timed out waiting for its controller wavefront)
+
+
+def test_fly_defaults_exit_test_and_cadence(torch_mod, oracle_mod):
+    """The random-fly step AT THE LIBRARY DEFAULTS (residual_threshold 1e-7, exit_check_stride 16: what bench.py --task random-fly runs): the
+    PGS exit test is live, evaluated at the sampled cadence.  One-step resynchronised against the oracle at the SAME cadence: iteration
+    counts equal (but for residuals sitting on the threshold), every env-step bounded by the ledger; and against the oracle at Bullet's
+    cadence (test after every iteration): the product runs 0 .. 15 further iterations, each below the threshold."""
+    torch = torch_mod
+    from tests import parity_util as P
+    N, steps = 256, 300
+    kw = dict(seed=11, dt=DT, auto_reset=1, max_episode_steps=150)
+    A = oracle_mod.FlyOracle(N, omp=True, **kw)                               # Bullet's cadence
+    B = oracle_mod.FlyOracle(N, omp=True, exit_check_stride=16, **kw)          # the product's
+    g = _gpu(N, debug=1, **kw)
+    assert g.cfg.exit_check_stride == 16 and abs(g.cfg.residual_threshold - 1e-7) < 1e-12
+    pk = dict(kw); pk["auto_reset"] = 0; pk["exit_check_stride"] = 16
+    led = P.ConditionedParity(oracle_mod, task="random-fly", slots=256, **pk)
+    rng = np.random.default_rng(3)
+    PW = [*range(0, 6), *range(18, 25)]; VW = [*range(6, 12), *range(25, 31)]
+    dA, dB, itB = [], [], []
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (N, 6))
+        s = B.get_state(); A.set_state(s); g.set_state(torch.tensor(s, dtype=torch.float32)); led.before(B)
+        A.step(a); _, rB, dnB = B.step(a)
+        _, rg, dg = g.step(torch.tensor(a, dtype=torch.float32))
+        so = B.get_state(); sg = g.state().cpu().numpy().astype(np.float64)
+        same = (dnB == dg.cpu().numpy()) & (so[:, 44] == sg[:, 44]) & (rB == rg.cpu().numpy())
+        live = same & (dnB == 0)
+        e_all = np.maximum(np.abs(so[:, PW] - sg[:, PW]).max(1), DT * np.abs(so[:, VW] - sg[:, VW]).max(1))
+        led.after(B, a, np.where(live, e_all, 0.0))
+        gi = g.debug().cpu().numpy()[:, 13].astype(int)
+        dA.append(np.where(live, gi - A.pgs_iters(), 0)); dB.append(np.where(live, gi - B.pgs_iters(), 0)); itB.append(B.pgs_iters().copy())
+    dA, dB, itB = map(np.concatenate, (dA, dB, itB))
+    led.finish("fly defaults (exit test live, cadence 16) N=%d" % N, p50=2e-6, p99=2e-5, exempt_share=0.02, check_force=False)
+    print("   early exit (same-cadence oracle < 50 iterations) in %.1f %% of the env-steps; product - oracle(same cadence) != 0 in %.3f %%; product - oracle(Bullet's cadence) min / max %d / %d" % (
+        100 * (itB < 50).mean(), 100 * (dB != 0).mean(), dA.min(), dA.max()))
+    assert (itB < 50).mean() > 0.3                         # the exit test fires in a large share of the env-steps (free flight, arm at rest)
+    assert (dB != 0).mean() < 1e-2 and dA.min() >= -1 and dA.max() <= 46      # never more than the gap between two tests (4 -> 20 -> 36 -> 50)
