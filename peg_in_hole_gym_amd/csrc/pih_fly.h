@@ -32,6 +32,20 @@ constexpr int CW = 24;             // words of one contact row record in lane me
 constexpr int KW = 8;              // words of one contact CANDIDATE of a slot (staged for the rolled row-build loop)
 constexpr int CAND0 = NC * CW;     // candidates follow the (compacted) row records
 constexpr int LANE_WORDS = NC * CW + NC * KW;
+// ONE ENV PER QUAD of lanes (round 4, `Q::QUAD`): everything up to the solver runs replicated in the four lanes (a wavefront issues the same
+// instructions whether 16 or 64 of its lanes hold distinct envs), the PGS sweep is split: lane s of the quad owns components 3 s .. 3 s + 2
+// of the 12-DOF velocity change (arm joints 0-2 | arm joints 3-5 | object linear | object angular) and, of every contact row, only its own
+// three Jacobian and three response entries.  A row's J . du is three multiply-adds plus a two-step quad all-reduce (DPP quad_perm: VALU
+// operand modifiers, no LDS), its update three multiply-adds: 12 VALU instructions and 9 LDS words per contact instead of 45 and 24.
+constexpr int CWQ = 9;             // words of a lane's share of one contact row: 0-2 J | 3-5 W | 6 dinv | 7 rhs | 8 lambda
+constexpr int LANE_WORDS_Q = NC * CWQ + NC * KW;
+struct NoQuad {                   // (the members are never called: they keep the discarded quad branches well-formed)
+  static constexpr bool QUAD = false;
+  PIH_HD int lane4() const { return 0; }
+  template <int K> PIH_HD real bcast(real x) const { return x; }
+  PIH_HD real xor1(real x) const { return x; }
+  PIH_HD real xor2(real x) const { return x; }
+};
 
 PIH_CONST real U_MASS[NJ] = PIH_UR5_MASS;
 PIH_CONST real U_COM[NJ][3] = PIH_UR5_COM;
@@ -142,6 +156,12 @@ struct RecordIk {      // the targets were written into the state record before 
 #define PIH_FLY_PIN24(R) ((void)0)
 #endif
 static_assert(CW == 24, "PIH_FLY_PIN24 names the 24 words of a contact record");
+#ifndef PIH_PLATFORM_DEFINED
+#define PIH_FLY_PIN9(R) __asm__ volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]), "+v"(R[8]))
+#else
+#define PIH_FLY_PIN9(R) ((void)0)
+#endif
+static_assert(CWQ == 9, "PIH_FLY_PIN9 names the 9 words of a lane's share of a contact record");
 
 // Diagnostic phase stamps (config.debug = 2, GPU only): shader-clock cycles since the previous stamp into debug word 900 + k of the env
 // (tools/fly_trace.py): 0 kinematics + inertias + collision candidates, 1 articulated-body sweeps, 2 motor response rows, 3 contact rows,
@@ -158,8 +178,11 @@ struct FlyStamp { FlyStamp(real*, bool) {} void operator()(int) {} };
 
 // One dt of one env.  S: the env's state record (a per-lane local array); mem: this lane's contact-row scratch; ctl: one of the above
 // (or the mailbox reader of the fused launch, pih_hip.hip).
-template <class Ctl = InlineIk, class Mem>
-PIH_HD void step_env(real* S, const Params& P, int env_global, const real* action, real* obs, real* reward, unsigned char* done, Mem mem, real* dbg, Ctl ctl = Ctl()) {
+// Q: NoQuad (one env per lane) or the quad primitives (QuadDpp / the host's lockstep threads, pih_ikq.h) of the one-env-per-quad layout.
+template <class Ctl = InlineIk, class Q = NoQuad, class Mem>
+PIH_HD void step_env(real* S, const Params& P, int env_global, const real* action, real* obs, real* reward, unsigned char* done, Mem mem, real* dbg, Ctl ctl = Ctl(), Q quad = Q()) {
+  constexpr int RW = Q::QUAD ? CWQ : CW;          // words of a contact record in this lane's memory
+  constexpr int CANDQ = NC * RW;                  // candidates follow the (compacted) row records
   const real dt = P.dt;
   const bool frozen = !P.autoreset && S[PIH_F_DONE] != 0;   // finished envs keep their last values (envs/base_env.py:62,66)
   bool landed = false;
@@ -347,7 +370,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       if (k < NS) { valid = clink[i] >= 0; la = clink[i]; n = cn[i]; p = cp[i]; depth = cdepth[i]; }
       else if (k < 2 * NS) { depth = sc[i].z - (real)PIH_TABLE_Z - srad[i]; valid = i < nsph && depth < P.margin; landed = landed || (i < nsph && depth < (real)0.002); la = -1; n = mk(0, 0, 1); p = mk(sc[i].x, sc[i].y, sc[i].z - srad[i] - (real)0.5 * depth); }
       else { depth = adepth[i]; valid = depth < P.margin; la = 1 + i; n = mk(0, 0, 1); p = apt[i]; }
-      const int b = CAND0 + k * KW;
+      const int b = CANDQ + k * KW;
       mem.at(b) = valid ? (real)(la + 2) : (real)0;
       mem.at(b + 1) = n.x; mem.at(b + 2) = n.y; mem.at(b + 3) = n.z; mem.at(b + 4) = p.x; mem.at(b + 5) = p.y; mem.at(b + 6) = p.z; mem.at(b + 7) = depth;
     }
@@ -358,7 +381,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
 #pragma nounroll
     for (int k = 0; k < NC; k++) {
       const bool armtab = k >= 2 * NS;
-      const int kb = CAND0 + k * KW;
+      const int kb = CANDQ + k * KW;
       const real tag = mem.at(kb);
       const bool valid = tag != (real)0;
       if (valid) {
@@ -383,11 +406,21 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         // object contacts: <contact_erp value="0.0"/> (banana.urdf:9, Amicelli_800_tex.urdf:9): a penetrating contact is stopped, not pushed out
         // [UNVERIFIED]; arm vs table: Bullet's default contact ERP (ur5.urdf has no <contact> block)
         const real vb = pen > 0 ? -pen / dt : (armtab ? -P.erp * pen / dt : (real)0);
-        const int b = nc * CW;
+        const int b = nc * RW;
+        if constexpr (Q::QUAD) {
+          const int s4 = quad.lane4();
+          const V3 wl = omass_inv * no;
+          const real j3[3] = {s4 == 0 ? J[0] : s4 == 1 ? J[3] : s4 == 2 ? no.x : rxn.x, s4 == 0 ? J[1] : s4 == 1 ? J[4] : s4 == 2 ? no.y : rxn.y, s4 == 0 ? J[2] : s4 == 1 ? J[5] : s4 == 2 ? no.z : rxn.z};
+          const real w3[3] = {s4 == 0 ? W[0] : s4 == 1 ? W[3] : s4 == 2 ? wl.x : wo.x, s4 == 0 ? W[1] : s4 == 1 ? W[4] : s4 == 2 ? wl.y : wo.y, s4 == 0 ? W[2] : s4 == 1 ? W[5] : s4 == 2 ? wl.z : wo.z};
+#pragma unroll
+          for (int t = 0; t < 3; t++) { mem.at(b + t) = j3[t]; mem.at(b + 3 + t) = w3[t]; }
+          mem.at(b + 6) = di; mem.at(b + 7) = (vb - ju) * di; mem.at(b + 8) = 0;
+        } else {
 #pragma unroll
         for (int L = 0; L < NJ; L++) { mem.at(b + L) = J[L]; mem.at(b + 6 + L) = W[L]; }
         mem.at(b + 12) = no.x; mem.at(b + 13) = no.y; mem.at(b + 14) = no.z; mem.at(b + 15) = rxn.x; mem.at(b + 16) = rxn.y; mem.at(b + 17) = rxn.z;
         mem.at(b + 18) = wo.x; mem.at(b + 19) = wo.y; mem.at(b + 20) = wo.z; mem.at(b + 21) = di; mem.at(b + 22) = (vb - ju) * di; mem.at(b + 23) = 0;
+        }
         if (dbg && P.debug) { real* d = dbg + 16 + 10 * k; d[0] = 1; d[1] = (real)la; d[2] = p.x; d[3] = p.y; d[4] = p.z; d[5] = n.x; d[6] = n.y; d[7] = n.z; d[8] = depth; d[9] = (real)nc; }
         nc++;
       } else if (dbg && P.debug) {
@@ -480,18 +513,96 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         }
       return worst;
     };
+    // The same sweep with one env per quad.  du3: this lane's three components of du; Wq[j]: its three entries of motor column j (zero in
+    // the two object lanes).  Row j needs du[j] from its owner (one quad_perm broadcast); the row's scalar arithmetic is replicated, so
+    // `worst` -- and with it the exit decision -- is identical in the four lanes.
+    real du3[3] = {0, 0, 0}, Wq[NJ][3], wjj[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      wjj[j] = Wm[j][j];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if constexpr (Q::QUAD) Wq[j][k] = quad.lane4() == 0 ? Wm[j][k] : quad.lane4() == 1 ? Wm[j][3 + k] : (real)0;
+        else Wq[j][k] = 0;
+      }
+    }
+    auto sweep_quad = [&](auto CHECKTAG) __attribute__((always_inline)) -> real {
+      constexpr bool CHECK = decltype(CHECKTAG)::value;
+      real worst = -1;
+      if constexpr (Q::QUAD) {
+        auto joint_rows = [&](auto JTAG) __attribute__((always_inline)) {
+          constexpr int j = decltype(JTAG)::value;
+          const real lim = U_EFFORT[j] * dt, di = mdi[j];
+          const real duj = quad.template bcast<(j / 3)>(du3[j % 3]);
+          real dl = mrhs[j] - duj * di, sum = med3_(lam_m[j] + dl, -lim, lim);
+          dl = sum - lam_m[j]; lam_m[j] = sum;
+          real tot = dl;
+          if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
+          real dj = duj + dl * wjj[j];
+          real d2 = lrl[j] - dj * di, s2 = max_(lam_lo[j] + d2, (real)0);
+          d2 = s2 - lam_lo[j]; lam_lo[j] = s2; tot += d2; dj += d2 * wjj[j];
+          if (CHECK) { const real v = d2 * d2 - P.resid * di * di; worst = v > worst ? v : worst; }
+          real d3 = lrh[j] + dj * di, s3 = max_(lam_hi[j] + d3, (real)0);
+          d3 = s3 - lam_hi[j]; lam_hi[j] = s3; tot -= d3;
+          if (CHECK) { const real v = d3 * d3 - P.resid * di * di; worst = v > worst ? v : worst; }
+  #pragma unroll
+          for (int k = 0; k < 3; k++) du3[k] += Wq[j][k] * tot;
+        };
+        joint_rows(std::integral_constant<int, 0>{}); joint_rows(std::integral_constant<int, 1>{}); joint_rows(std::integral_constant<int, 2>{});
+        joint_rows(std::integral_constant<int, 3>{}); joint_rows(std::integral_constant<int, 4>{}); joint_rows(std::integral_constant<int, 5>{});
+        auto load_rec = [&](real* R, int c) __attribute__((always_inline)) {
+  #pragma unroll
+          for (int i = 0; i < CWQ; i++) R[i] = mem.at(c * CWQ + i);
+        };
+        auto solve_rec = [&](real* R, int c) __attribute__((always_inline)) {
+          PIH_FLY_PIN9(R);
+          real jd = R[0] * du3[0] + R[1] * du3[1] + R[2] * du3[2];
+          jd += quad.xor1(jd); jd += quad.xor2(jd);
+          const real di = R[6], lam = R[8];
+          real dl = R[7] - jd * di;
+          const real sum = max_(lam + dl, (real)0);
+          dl = sum - lam; mem.at(c * CWQ + 8) = sum;
+  #pragma unroll
+          for (int k = 0; k < 3; k++) du3[k] += R[3 + k] * dl;
+          if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
+        };
+        static_assert((NC + 2) * CWQ <= LANE_WORDS_Q, "the read-ahead of up to two records stays inside the lane's words");
+        if (nc > 0) {
+          real Ra[CWQ], Rb[CWQ];
+          load_rec(Ra, 0);
+          for (int c = 0; c < nc; c += 2) {
+            load_rec(Rb, c + 1);
+            solve_rec(Ra, c);
+            load_rec(Ra, c + 2);
+            if (c + 1 < nc) solve_rec(Rb, c + 1);
+          }
+        }
+      }
+      return worst;
+    };
     int it = 0;
     for (; it < P.iters; it++) {
       const int i1 = it + 1;
       const bool chk = P.checkstride <= 1 || i1 <= 4 || i1 == P.iters || (i1 - 4) % P.checkstride == 0;
-      if (chk) { if (sweep(std::true_type{}) <= 0) { it++; break; } }
-      else sweep(std::false_type{});
+      if constexpr (Q::QUAD) {
+        if (chk) { if (sweep_quad(std::true_type{}) <= 0) { it++; break; } }
+        else sweep_quad(std::false_type{});
+      } else {
+        if (chk) { if (sweep(std::true_type{}) <= 0) { it++; break; } }
+        else sweep(std::false_type{});
+      }
+    }
+    if constexpr (Q::QUAD) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        du[k] = quad.template bcast<0>(du3[k]); du[3 + k] = quad.template bcast<1>(du3[k]); du[6 + k] = quad.template bcast<2>(du3[k]); du[9 + k] = quad.template bcast<3>(du3[k]);
+      }
     }
     real cf = 0;
-    for (int c = 0; c < nc; c++) cf += mem.at(c * CW + 23);
+    for (int c = 0; c < nc; c++) cf += mem.at(c * RW + RW - 1);
     if (dbg && P.debug) {
       dbg[12] = (real)nc; dbg[13] = (real)it;
-      for (int c = 0; c < nc; c++) dbg[200 + c] = mem.at(c * CW + 23);    // lambda_n of compacted contact c (contact records occupy words 16 .. 16 + 10 NC)
+      for (int c = 0; c < nc; c++) dbg[200 + c] = mem.at(c * RW + RW - 1);    // lambda_n of compacted contact c (contact records occupy words 16 .. 16 + 10 NC)
     }
     stamp(5);
     // ---- integrate

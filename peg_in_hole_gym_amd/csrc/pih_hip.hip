@@ -337,6 +337,7 @@ __global__ void __launch_bounds__(256) pih_fly_pre_kernel(Params P, float* __res
 // sweeps, collision detection and all response rows, i.e. later than the 24 us the IK takes.  Every workgroup of the launch carries the
 // step's 120 KB of dynamic LDS, so the layout is used only while 2 G workgroups fit the chip's CUs at once (n <= 8192); bigger batches
 // run the IK inside the step wavefront (MODE 0).  MODE 1: targets from a pre-launch (pih_fly_pre_kernel; measurement switch).
+#define PIH_FLY_QUAD_MAX_ENVS 4096
 struct FlyFused { int G, epoch; float* mail; int* flags; int* err; };
 struct MailboxIk {
   const int* flag; const float* mail; int* err; int epoch, env, n;
@@ -351,7 +352,10 @@ struct MailboxIk {
     for (int i = 0; i < fly::NJ; i++) qs[i] = __hip_atomic_load(mail + (size_t)i * n + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 };
-template <int MODE>
+// QUAD: one env per quad of lanes (pih_fly.h): a step wavefront holds 16 envs, the PGS sweep is split over the quad; the controller
+// wavefronts stay one env per lane, so one flag covers four step wavefronts.
+struct FlyQuad : QuadDpp { static constexpr bool QUAD = true; };
+template <int MODE, bool QUAD = false>
 __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
                                                              float* __restrict__ obs, float* __restrict__ reward,
                                                              unsigned char* __restrict__ done, float* __restrict__ dbg, int n, FlyFused F) {
@@ -378,8 +382,9 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
     return;
   }
   const int blk = MODE == 2 ? blockIdx.x - F.G : blockIdx.x;
-  const int env = blk * 64 + threadIdx.x;
+  const int env = QUAD ? blk * 16 + (int)(threadIdx.x >> 2) : blk * 64 + (int)threadIdx.x;
   if (env >= n) return;
+  const bool writer = !QUAD || (threadIdx.x & 3) == 0;      // (the four lanes of a quad hold identical results)
   // config.debug = 2: start / end of the wavefront on the chip-wide 100 MHz clock and where it ran (debug words 940 .. 947 of the wave's
   // first env; tools/fly_trace.py) -- never read by the kernel
   const bool stamp = dbg && P.debug == 2 && threadIdx.x == 0;
@@ -397,18 +402,21 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
   fly::LaneMem mem; mem.p = lanemem + threadIdx.x; mem.stride = 64;
   float* dbge = dbg ? dbg + (size_t)env * PIH_DEBUG_WORDS : nullptr;
   if constexpr (MODE == 2) {
-    MailboxIk mb; mb.flag = F.flags + blk; mb.mail = F.mail; mb.err = F.err; mb.epoch = F.epoch; mb.env = env; mb.n = n;
-    fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, mb);
+    MailboxIk mb; mb.flag = F.flags + (env >> 6); mb.mail = F.mail; mb.err = F.err; mb.epoch = F.epoch; mb.env = env; mb.n = n;
+    if constexpr (QUAD) { FlyQuad qd; qd.l = threadIdx.x & 3; fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, mb, qd); }
+    else fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, mb);
   } else if constexpr (MODE == 1) fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::RecordIk());
   else fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::InlineIk());
+  if (writer) {
 #pragma unroll
-  for (int w = 0; w < fly::SW; w++) state[(size_t)w * n + env] = S[w];
-  if (obs) {
+    for (int w = 0; w < fly::SW; w++) state[(size_t)w * n + env] = S[w];
+    if (obs) {
 #pragma unroll
-    for (int k = 0; k < PIH_FLY_OBS_DIM; k++) obs[(size_t)env * PIH_FLY_OBS_DIM + k] = o[k];
+      for (int k = 0; k < PIH_FLY_OBS_DIM; k++) obs[(size_t)env * PIH_FLY_OBS_DIM + k] = o[k];
+    }
+    if (reward) reward[env] = r;
+    if (done) done[env] = d;
   }
-  if (reward) reward[env] = r;
-  if (done) done[env] = d;
   if (stamp) {
     const long long ts1 = (long long)__builtin_amdgcn_s_memrealtime();
     float* o2 = dbg + (size_t)env * PIH_DEBUG_WORDS;
@@ -602,6 +610,7 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS_Q * 64 * sizeof(float))));
     {
       // fused launch (controller wavefronts + step wavefronts in one grid) while both sets of workgroups -- each with the step's 120 KB of
       // LDS -- fit the chip's CUs at once; schedule + 8: IK inside the step wavefront, + 16: IK as a quad-per-env pre-launch (switches)
@@ -732,7 +741,11 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
       if (*h->errw_host) { h->err = CTRL_TIMEOUT_MSG; return -5; }
       FF.G = G; FF.epoch = ++h->epoch; FF.mail = h->mail; FF.flags = h->flags; FF.err = h->errw;
       if (t) HIPCHK(h, hipEventRecord(t->b, s));
-      hipLaunchKernelGGL(pih_fly_step_kernel<2>, dim3(2 * G), dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
+      // one env per QUAD while the chip has a CU slot per 16 envs (two 64 KB workgroups per CU); schedule + 32: one env per lane (A/B)
+      if (h->cfg.n_envs <= PIH_FLY_QUAD_MAX_ENVS && !(h->cfg.schedule & 32))
+        hipLaunchKernelGGL((pih_fly_step_kernel<2, true>), dim3(G + (h->cfg.n_envs + 15) / 16), dim3(64), (size_t)fly::LANE_WORDS_Q * 64 * sizeof(float), s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
+      else
+        hipLaunchKernelGGL(pih_fly_step_kernel<2>, dim3(2 * G), dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
     } else if (h->cfg.schedule & 16) {
       hipLaunchKernelGGL(pih_fly_pre_kernel, dim3(G), dim3(256), 0, s, h->P, h->state, actions, h->cfg.n_envs);
       if (t) HIPCHK(h, hipEventRecord(t->b, s));

@@ -62,6 +62,8 @@ def lib(prec):
         L.emul_fly_destroy.argtypes = [C.c_void_p]
         L.emul_fly_reset.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
         L.emul_fly_step.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_uint8)]
+        L.emul_fly_step_quad.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_uint8)]
+        L.emul_fly_step_quad.restype = C.c_int
         L.emul_fly_get_state.argtypes = [C.c_void_p, dp]
         L.emul_fly_set_state.argtypes = [C.c_void_p, dp]
         L.emul_fly_get_debug.argtypes = [C.c_void_p, dp]
@@ -155,6 +157,13 @@ class EmulFly:
         obs = np.zeros((self.n, 6)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.uint8)
         self.L.emul_fly_step(self.h, _dp(a), _dp(obs), _dp(rew), done.ctypes.data_as(C.POINTER(C.c_uint8)))
         return obs, rew, done
+
+    def step_quad(self, actions):
+        """the one-env-per-quad layout (four host threads in lockstep per env); also returns the number of envs whose four lanes disagree"""
+        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n, 6)
+        obs = np.zeros((self.n, 6)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.uint8)
+        bad = self.L.emul_fly_step_quad(self.h, _dp(a), _dp(obs), _dp(rew), done.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return obs, rew, done, int(bad)
 
     def get_state(self):
         s = np.zeros((self.n, 48)); self.L.emul_fly_get_state(self.h, _dp(s)); return s

@@ -47,6 +47,7 @@ struct QuadHost {
   real xor1(real x) const { return from(x, l ^ 1); }
   real xor2(real x) const { return from(x, l ^ 2); }
 };
+struct FlyQuadHost : QuadHost { static constexpr bool QUAD = true; };
 template <class C> static void ikq_host(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout, double* ee_out) {
   const Params P = make_params(c);
   QuadShared sh;
@@ -168,6 +169,37 @@ void emul_fly_step(void* h, const double* actions, double* obs, double* reward, 
     for (int k = 0; k < 6; k++) obs[6 * i + k] = (double)o[k];
     reward[i] = (double)r; done[i] = d;
   }
+}
+// the one-env-per-quad layout of the same step (pih_fly.h `Q::QUAD`): the four lanes of a quad are four host threads in lockstep (QuadHost
+// above), each with its own copy of the state record and its own lane memory; lane 0's results are kept, and the four copies are compared
+// (return value: the number of envs whose four lanes did NOT finish with bit-identical records -- 0 by construction)
+int emul_fly_step_quad(void* h, const double* actions, double* obs, double* reward, unsigned char* done) {
+  EmulFly* e = (EmulFly*)h;
+  QuadShared sh;
+  std::vector<real> out((size_t)4 * e->n * PIH_FLY_STATE_WORDS);
+  std::thread th[4];
+  for (int l = 0; l < 4; l++) th[l] = std::thread([&, l]() {
+    FlyQuadHost qd; qd.l = l; qd.sh = &sh;
+    std::vector<real> lanemem(fly::LANE_WORDS_Q), dbg(PIH_DEBUG_WORDS);
+    for (int i = 0; i < e->n; i++) {
+      real S[PIH_FLY_STATE_WORDS], a[6], o[6], r; unsigned char d;
+      for (int k = 0; k < PIH_FLY_STATE_WORDS; k++) S[k] = e->state[(size_t)i * PIH_FLY_STATE_WORDS + k];
+      for (int k = 0; k < 6; k++) a[k] = (real)actions[6 * i + k];
+      fly::LaneMem mem; mem.p = lanemem.data(); mem.stride = 1;
+      fly::step_env(S, e->P, e->P.env0 + i, a, o, &r, &d, mem, l == 0 ? &e->dbg[(size_t)i * PIH_DEBUG_WORDS] : dbg.data(), fly::InlineIk(), qd);
+      for (int k = 0; k < PIH_FLY_STATE_WORDS; k++) out[((size_t)l * e->n + i) * PIH_FLY_STATE_WORDS + k] = S[k];
+      if (l == 0) { for (int k = 0; k < 6; k++) obs[6 * i + k] = (double)o[k]; reward[i] = (double)r; done[i] = d; }
+    }
+  });
+  for (int l = 0; l < 4; l++) th[l].join();
+  int bad = 0;
+  for (int i = 0; i < e->n; i++) {
+    bool same = true;
+    for (int l = 1; l < 4; l++) same = same && memcmp(&out[((size_t)l * e->n + i) * PIH_FLY_STATE_WORDS], &out[(size_t)i * PIH_FLY_STATE_WORDS], sizeof(real) * PIH_FLY_STATE_WORDS) == 0;
+    bad += same ? 0 : 1;
+    for (int k = 0; k < PIH_FLY_STATE_WORDS; k++) e->state[(size_t)i * PIH_FLY_STATE_WORDS + k] = out[(size_t)i * PIH_FLY_STATE_WORDS + k];
+  }
+  return bad;
 }
 void emul_fly_get_state(void* h, double* out) { EmulFly* e = (EmulFly*)h; for (size_t i = 0; i < e->state.size(); i++) out[i] = (double)e->state[i]; }
 void emul_fly_set_state(void* h, const double* in) { EmulFly* e = (EmulFly*)h; for (size_t i = 0; i < e->state.size(); i++) e->state[i] = (real)in[i]; }

@@ -302,3 +302,34 @@ def test_fly_exit_cadence_host_build_matches_same_cadence_oracle(oracle_mod):
         dA.append((it - A.pgs_iters())[live]); early += int((B.pgs_iters()[live] < 50).sum())
     dA = np.concatenate(dA)
     assert early > 500 and dA.min() >= 0 and dA.max() <= 46 and (dA > 0).any()
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_fly_quad_layout_host_build(oracle_mod, prec):
+    """One env per QUAD of lanes (pih_fly.h Q::QUAD; the GPU layout up to 4096 envs), host build with four lockstep threads per env: the four
+    lanes of every quad end each step with bit-identical records; against the one-env-per-lane build of the same source only the association
+    of the sums differs (fp64: 1e-9 one-step, the bound of the lane build against the oracle where an arm link is pressed into the table);
+    contact counts, iteration counts, rewards and done flags are identical; against the oracle as the lane build."""
+    O = oracle_mod
+    n = 12
+    kw = dict(seed=4, dt=DT, auto_reset=1, max_episode_steps=120, exit_check_stride=16)
+    o = O.FlyOracle(n, **kw); a = E.EmulFly(n, prec, debug=1, **kw); b = E.EmulFly(n, prec, debug=1, **kw)
+    rng = np.random.default_rng(6)
+    ncs = 0; err_l = []; err_o = []; its = 0
+    for t in range(150):
+        act = rng.uniform(-1, 1, (n, 6))
+        s = o.get_state(); a.set_state(s); b.set_state(s)
+        oo, ro, do = o.step(act); oa, ra, da = a.step(act); ob, rb, db, bad = b.step_quad(act)
+        assert bad == 0
+        sa, sb, so = a.get_state(), b.get_state(), o.get_state()
+        np.testing.assert_array_equal(da, db); np.testing.assert_array_equal(ra, rb); np.testing.assert_array_equal(sa[:, 44], sb[:, 44])
+        live = (do == 0) & (da == 0)
+        ia, ib = a.get_debug()[:, 13], b.get_debug()[:, 13]
+        its += int((ia[live] != ib[live]).sum())
+        ncs += int(sb[:, 44].sum())
+        err_l.append(np.abs(sa[live][:, :31] - sb[live][:, :31]).max(initial=0)); err_o.append(np.abs(so[live][:, :31] - sb[live][:, :31]).max(initial=0))
+        np.testing.assert_allclose(oa, ob, atol=1e-9 if prec == "f64" else 2e-4)
+    print(prec, "quad vs lane layout max %.2e, quad vs oracle max %.2e median %.2e; contact env-steps %d; iteration counts differing %d" % (max(err_l), max(err_o), np.median(err_o), ncs, its))
+    assert ncs > 100
+    assert max(err_l) < (5e-8 if prec == "f64" else 2e-3) and max(err_o) < (5e-8 if prec == "f64" else 2e-3)
+    assert np.median(err_o) < (2e-9 if prec == "f64" else 5e-5) and its <= 2

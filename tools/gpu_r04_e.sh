@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 4, session E: random-fly with one env per QUAD of lanes -- fly tests, timeline, bench lines (quad default vs lane layout)
+TAG=${1:-r04k}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
+timeout -k 10 600 python -m pytest tests/test_gpu_fly.py -m gpu -q -s -x --durations=5 > $O/gpu_tests_$TAG.log 2>&1; rc=$?
+tail -8 $O/gpu_tests_$TAG.log
+[ $rc -ne 0 ] && { echo "GPU TESTS FAILED rc=$rc"; grep -nE "^(FAILED|ERROR)|Error|assert" $O/gpu_tests_$TAG.log | head -30; exit 1; }
+grep -n "quad vs lane" $O/gpu_tests_$TAG.log
+for cfg in "fly:--task random-fly --no-cpu-baseline" "fly_lane:--task random-fly --no-cpu-baseline --schedule 33" "fly1024:--task random-fly --envs 1024 --no-cpu-baseline" "fly2048:--task random-fly --envs 2048 --no-cpu-baseline" "fly8192:--task random-fly --envs 8192 --no-cpu-baseline"; do
+  name=${cfg%%:*}; args=${cfg#*:}
+  timeout -k 10 300 python bench.py $args > $O/bench_${TAG}_$name.json 2> $O/bench_${TAG}_$name.err || { echo "BENCH $name FAILED"; tail -20 $O/bench_${TAG}_$name.err; exit 1; }
+  python - <<PY
+import json
+d = json.loads(open("$O/bench_${TAG}_$name.json").read().strip().splitlines()[-1])
+print("$name: %.3f M env-steps/s step %.4f ms kernel %.4f ms" % (d["value"] / 1e6, d["ms_per_step"], d["roofline"]["kernel_avg_ms"]))
+PY
+done
