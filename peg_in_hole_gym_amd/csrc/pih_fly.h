@@ -39,12 +39,14 @@ constexpr int LANE_WORDS = NC * CW + NC * KW;
 // operand modifiers, no LDS), its update three multiply-adds: 12 VALU instructions and 9 LDS words per contact instead of 45 and 24.
 constexpr int CWQ = 9;             // words of a lane's share of one contact row: 0-2 J | 3-5 W | 6 dinv | 7 rhs | 8 lambda
 constexpr int LANE_WORDS_Q = NC * CWQ + NC * KW;
+constexpr int KR = 8;              // quad layout: the records of the first KR contacts of an env stay in REGISTERS over the PGS iterations (72 per lane)
 struct NoQuad {                   // (the members are never called: they keep the discarded quad branches well-formed)
   static constexpr bool QUAD = false;
   PIH_HD int lane4() const { return 0; }
   template <int K> PIH_HD real bcast(real x) const { return x; }
   PIH_HD real xor1(real x) const { return x; }
   PIH_HD real xor2(real x) const { return x; }
+  PIH_HD int wave_max(int x) const { return x; }
 };
 
 PIH_CONST real U_MASS[NJ] = PIH_UR5_MASS;
@@ -428,6 +430,20 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         for (int t = 0; t < 10; t++) d[t] = 0;
       }
     }
+    // Quad layout: the lane's share of the first KR contact records moves from lane memory into registers (zeros beyond the env's last
+    // contact: such a row computes dl = 0), requested BEFORE the wait for the IK targets.  Through LDS a contact cost ~ 225 cycles per
+    // iteration although it is 25 instructions: the ~ 200-cycle round trip of a batch of record reads was not covered by one contact's
+    // arithmetic (gpurun_out/fly_trace_r04k.txt: 450 cycles per pair of contacts).  ncw: the largest contact count of the wavefront.
+    real Rr[KR][CWQ - 1], lamr[KR]; int ncw = 0;
+    if constexpr (Q::QUAD) {
+      ncw = quad.wave_max(nc);
+#pragma unroll
+      for (int c = 0; c < KR; c++) {
+#pragma unroll
+        for (int i = 0; i < CWQ - 1; i++) { const real v = mem.at(c * CWQ + i); Rr[c][i] = c < nc ? v : (real)0; }
+        lamr[c] = 0;
+      }
+    }
     stamp(3);
     // ---- controller: ur_execute (envs/utils.py:70-82): IK targets -> POSITION_CONTROL target velocities -> right-hand sides of the motor rows
     {
@@ -550,31 +566,35 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         };
         joint_rows(std::integral_constant<int, 0>{}); joint_rows(std::integral_constant<int, 1>{}); joint_rows(std::integral_constant<int, 2>{});
         joint_rows(std::integral_constant<int, 3>{}); joint_rows(std::integral_constant<int, 4>{}); joint_rows(std::integral_constant<int, 5>{});
-        auto load_rec = [&](real* R, int c) __attribute__((always_inline)) {
   #pragma unroll
-          for (int i = 0; i < CWQ; i++) R[i] = mem.at(c * CWQ + i);
-        };
-        auto solve_rec = [&](real* R, int c) __attribute__((always_inline)) {
-          PIH_FLY_PIN9(R);
-          real jd = R[0] * du3[0] + R[1] * du3[1] + R[2] * du3[2];
-          jd += quad.xor1(jd); jd += quad.xor2(jd);
-          const real di = R[6], lam = R[8];
-          real dl = R[7] - jd * di;
-          const real sum = max_(lam + dl, (real)0);
-          dl = sum - lam; mem.at(c * CWQ + 8) = sum;
+        for (int c = 0; c < KR; c++) {
+          if (c < ncw) {                     // (wave-uniform)
+            real jd = Rr[c][0] * du3[0] + Rr[c][1] * du3[1] + Rr[c][2] * du3[2];
+            jd += quad.xor1(jd); jd += quad.xor2(jd);
+            const real di = Rr[c][6];
+            real dl = Rr[c][7] - jd * di;
+            const real sum = max_(lamr[c] + dl, (real)0);
+            dl = sum - lamr[c]; lamr[c] = sum;
   #pragma unroll
-          for (int k = 0; k < 3; k++) du3[k] += R[3 + k] * dl;
-          if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
-        };
-        static_assert((NC + 2) * CWQ <= LANE_WORDS_Q, "the read-ahead of up to two records stays inside the lane's words");
-        if (nc > 0) {
-          real Ra[CWQ], Rb[CWQ];
-          load_rec(Ra, 0);
-          for (int c = 0; c < nc; c += 2) {
-            load_rec(Rb, c + 1);
-            solve_rec(Ra, c);
-            load_rec(Ra, c + 2);
-            if (c + 1 < nc) solve_rec(Rb, c + 1);
+            for (int k = 0; k < 3; k++) du3[k] += Rr[c][3 + k] * dl;
+            if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
+          }
+        }
+        // contacts KR .. (rare: a ninth contact of one env): from lane memory
+        if (ncw > KR) {
+          for (int c = KR; c < nc; c++) {
+            real R[CWQ];
+  #pragma unroll
+            for (int i = 0; i < CWQ; i++) R[i] = mem.at(c * CWQ + i);
+            real jd = R[0] * du3[0] + R[1] * du3[1] + R[2] * du3[2];
+            jd += quad.xor1(jd); jd += quad.xor2(jd);
+            const real di = R[6], lam = R[8];
+            real dl = R[7] - jd * di;
+            const real sum = max_(lam + dl, (real)0);
+            dl = sum - lam; mem.at(c * CWQ + 8) = sum;
+  #pragma unroll
+            for (int k = 0; k < 3; k++) du3[k] += R[3 + k] * dl;
+            if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
           }
         }
       }
@@ -593,6 +613,8 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       }
     }
     if constexpr (Q::QUAD) {
+#pragma unroll
+      for (int c = 0; c < KR; c++) if (c < nc) mem.at(c * CWQ + 8) = lamr[c];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         du[k] = quad.template bcast<0>(du3[k]); du[3 + k] = quad.template bcast<1>(du3[k]); du[6 + k] = quad.template bcast<2>(du3[k]); du[9 + k] = quad.template bcast<3>(du3[k]);

@@ -354,7 +354,15 @@ struct MailboxIk {
 };
 // QUAD: one env per quad of lanes (pih_fly.h): a step wavefront holds 16 envs, the PGS sweep is split over the quad; the controller
 // wavefronts stay one env per lane, so one flag covers four step wavefronts.
-struct FlyQuad : QuadDpp { static constexpr bool QUAD = true; };
+struct FlyQuad : QuadDpp {
+  static constexpr bool QUAD = true;
+  __device__ __forceinline__ int wave_max(int x) const {     // the largest x of the wavefront's active lanes (0 <= x <= fly::NC), as a scalar
+    int m = 0;
+#pragma unroll
+    for (int k = 1; k <= fly::NC; k++) if (__builtin_amdgcn_ballot_w64(x >= k) != 0) m = k;
+    return __builtin_amdgcn_readfirstlane(m);
+  }
+};
 template <int MODE, bool QUAD = false>
 __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
                                                              float* __restrict__ obs, float* __restrict__ reward,

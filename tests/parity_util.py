@@ -394,3 +394,21 @@ class ForceLedger:
         assert not over.any(), "%s: |dF| exceeds %.0f x the oracle's own probe deviation on %d transient steps" % (name, self.K_SPREAD, over.sum())
         assert trans.mean() <= transient_share and avg <= self.tol
         return dict(calm_max=calm_max, transients=int(trans.sum()), avg=avg, inst_max=float(d.max()))
+
+
+def fly_many_contact_states(sim, n, seed=0):
+    """random-fly states with 5 .. 14 contacts (random arm poses lying on the table, the object flat on the table at the end effector): the
+    cases beyond the 8 contact records the one-env-per-quad layout keeps in registers (pih_fly.h KR).  sim: anything with get_state /
+    set_state / step (oracle.FlyOracle, the host build); it is stepped twice and left in an arbitrary state."""
+    rng = np.random.default_rng(seed)
+    s = sim.get_state()
+    s[:, 0] = rng.uniform(-3, 3, n); s[:, 1] = rng.uniform(-0.3, 0.3, n); s[:, 2] = rng.uniform(-0.5, 0.5, n)
+    for k in (3, 4, 5):
+        s[:, k] = rng.uniform(-3, 3, n)
+    s[:, 6:12] = 0; s[:, 31] = 0; s[:, 32] = 0
+    sim.set_state(s); sim.step(np.zeros((n, 6)))
+    ee = sim.get_state()[:, 40:43] - s[:, 35:38]
+    s[:, 18] = ee[:, 0] + rng.uniform(-0.05, 0.05, n); s[:, 19] = ee[:, 1] + rng.uniform(-0.05, 0.05, n); s[:, 20] = -0.05 + 0.03
+    yaw = rng.uniform(-3, 3, n); s[:, 21] = 0; s[:, 22] = 0; s[:, 23] = np.sin(yaw / 2); s[:, 24] = np.cos(yaw / 2)
+    s[:, 25:31] = 0
+    return s

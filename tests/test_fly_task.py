@@ -333,3 +333,28 @@ def test_fly_quad_layout_host_build(oracle_mod, prec):
     assert ncs > 100
     assert max(err_l) < (5e-8 if prec == "f64" else 2e-3) and max(err_o) < (5e-8 if prec == "f64" else 2e-3)
     assert np.median(err_o) < (2e-9 if prec == "f64" else 5e-5) and its <= 2
+
+
+def test_fly_quad_layout_more_contacts_than_register_records(oracle_mod):
+    """the quad layout keeps the first 8 contact records of an env in registers and sweeps a 9th .. 15th from lane memory: states with
+    5 .. 14 contacts (arm lying on the table, object under the hand), host build in both layouts and the oracle"""
+    from tests import parity_util as P
+    O = oracle_mod
+    n = 48
+    kw = dict(seed=4, dt=DT, auto_reset=0, max_episode_steps=100000, exit_check_stride=16, contact_margin=0.02)
+    o = O.FlyOracle(n, **kw); a = E.EmulFly(n, "f64", debug=1, **kw); b = E.EmulFly(n, "f64", debug=1, **kw)
+    s = P.fly_many_contact_states(o, n, seed=1)
+    o.set_state(s); a.set_state(s); b.set_state(s)
+    big = 0
+    for t in range(6):
+        act = np.zeros((n, 6)); act[:, :3] = [0.3, 0.0, 0.3]
+        o.set_state(a.get_state()); b.set_state(a.get_state())
+        o.step(act); a.step(act); _, _, _, bad = b.step_quad(act)
+        assert bad == 0
+        sa, sb, so = a.get_state(), b.get_state(), o.get_state()
+        np.testing.assert_array_equal(sa[:, 44], sb[:, 44]); np.testing.assert_array_equal(sa[:, 44], so[:, 44])
+        big += int((sb[:, 44] > 8).sum())
+        np.testing.assert_array_equal(a.get_debug()[:, 13], b.get_debug()[:, 13])
+        assert np.abs(sa[:, :31] - sb[:, :31]).max() < 1e-9 and np.abs(so[:, :31] - sb[:, :31]).max() < 1e-6
+        assert np.abs(sa[:, 43] - sb[:, 43]).max() < 1e-6 * (1 + np.abs(sa[:, 43]).max())         # the summed normal force
+    assert big >= 30
