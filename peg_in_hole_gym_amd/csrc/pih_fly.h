@@ -47,6 +47,7 @@ struct NoQuad {                   // (the members are never called: they keep th
   PIH_HD real xor1(real x) const { return x; }
   PIH_HD real xor2(real x) const { return x; }
   PIH_HD int wave_max(int x) const { return x; }
+  PIH_HD int wave_or(int x) const { return x; }
 };
 
 PIH_CONST real U_MASS[NJ] = PIH_UR5_MASS;
@@ -458,36 +459,70 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
     }
     stamp(4);
     // ---- sequential impulse: per joint (motor, lower limit, upper limit), then the contact normals
-    real du[FND];
+    real du[FND], lam_m[NJ], lam_lo[NJ], lam_hi[NJ], wjj[NJ];
+    // Quad layout.  du3: this lane's three components of du; Wq[j]: its three entries of motor column j (zero in the two object lanes).
+    // Row j needs du[j] from its owner (one quad_perm broadcast); the row's scalar arithmetic is replicated, so `worst` -- and with it the
+    // exit decision -- is identical in the four lanes.
+    real du3[3], Wq[NJ][3];
 #pragma unroll
-    for (int i = 0; i < FND; i++) du[i] = 0;
-    real lam_m[NJ], lam_lo[NJ], lam_hi[NJ];
+    for (int j = 0; j < NJ; j++) {
+      wjj[j] = Wm[j][j];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) { lam_m[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
+      for (int k = 0; k < 3; k++) {
+        if constexpr (Q::QUAD) Wq[j][k] = quad.lane4() == 0 ? Wm[j][k] : quad.lane4() == 1 ? Wm[j][3 + k] : (real)0;
+        else Wq[j][k] = 0;
+      }
+    }
+    // SPECULATE AND VERIFY on the joint-limit rows.  A limit row whose multiplier is zero and whose right-hand side stays <= 0 is a no-op,
+    // and that is every limit row of a joint that cannot reach its limit within this step -- but the three rows of a joint are one
+    // dependent chain (17 instructions; a lone wavefront waits ~ 8 cycles for each), 6 joints per sweep.  So: joints closer than
+    // LIMIT_REACH to a limit (in any env of the wavefront: `limmask`, wave-uniform) run all three rows; for the others only the motor row
+    // runs, and the two right-hand sides the skipped rows would have seen are tracked (`viol`, exactly the expressions of the full rows,
+    // off the dependent chain).  If one of them ever turns positive the skipped row would have acted: that env's solve is discarded and
+    // repeated with all rows (pass 1).  Results are those of the full sweep, bit for bit, either way.
+    constexpr real LIMIT_REACH = (real)0.5;            // [rad]: 60 rad/s for one step of 1/120 s
+    int limmask = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) if (q[j] - U_LO[j] < LIMIT_REACH || U_HI[j] - q[j] < LIMIT_REACH) limmask |= 1 << j;
+    limmask = quad.wave_or(limmask);
+    real viol = -1;
+    // the three rows of joint j given du[j]; returns the joint's total impulse change
+    auto joint_tot = [&](auto JTAG, real duj, auto CHECKTAG, real& worst) __attribute__((always_inline)) -> real {
+      constexpr int j = decltype(JTAG)::value;
+      constexpr bool CHECK = decltype(CHECKTAG)::value;
+      const real lim = U_EFFORT[j] * dt, di = mdi[j];
+      real dl = mrhs[j] - duj * di, sum = med3_(lam_m[j] + dl, -lim, lim);
+      dl = sum - lam_m[j]; lam_m[j] = sum;
+      if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
+      real dj = duj + dl * wjj[j];
+      if (!((limmask >> j) & 1)) {                     // (wave-uniform)
+        const real r2 = lrl[j] - dj * di, r3 = lrh[j] + dj * di;
+        viol = max_(viol, max_(r2, r3));
+        return dl;
+      }
+      real tot = dl;
+      real d2 = lrl[j] - dj * di, s2 = max_(lam_lo[j] + d2, (real)0);
+      d2 = s2 - lam_lo[j]; lam_lo[j] = s2; tot += d2; dj += d2 * wjj[j];
+      if (CHECK) { const real v = d2 * d2 - P.resid * di * di; worst = v > worst ? v : worst; }
+      real d3 = lrh[j] + dj * di, s3 = max_(lam_hi[j] + d3, (real)0);
+      d3 = s3 - lam_hi[j]; lam_hi[j] = s3; tot -= d3;
+      if (CHECK) { const real v = d3 * d3 - P.resid * di * di; worst = v > worst ? v : worst; }
+      return tot;
+    };
     // One sweep over the rows; CHECK: also Bullet's exit test -- the largest squared row residual against residual_threshold.  The test
     // runs at the cadence of pih_config.exit_check_stride, as in the peg-in-hole solvers (include/pih.h): 1 = after every iteration
-    // (Bullet); s > 1 = iterations 1 .. 4, 4 + s k and the last one (default 16).  Every wavefront runs to the iteration count of its
-    // slowest lane anyway (49 - 50 of 50 with 64 envs per wave), so the 42 instructions the test costs per sweep bought nothing.
+    // (Bullet); s > 1 = iterations 1 .. 4, 4 + s k and the last one (default 16).
     auto sweep = [&](auto CHECKTAG) __attribute__((always_inline)) -> real {
       constexpr bool CHECK = decltype(CHECKTAG)::value;
       real worst = -1;
+      auto joint_rows = [&](auto JTAG) __attribute__((always_inline)) {
+        constexpr int j = decltype(JTAG)::value;
+        const real tot = joint_tot(JTAG, du[j], CHECKTAG, worst);
   #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-          const real lim = U_EFFORT[j] * dt, di = mdi[j];
-          real dl = mrhs[j] - du[j] * di, sum = med3_(lam_m[j] + dl, -lim, lim);
-          dl = sum - lam_m[j]; lam_m[j] = sum;
-          real tot = dl;
-          if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
-          real dj = du[j] + dl * Wm[j][j];
-          real d2 = lrl[j] - dj * di, s2 = max_(lam_lo[j] + d2, (real)0);
-          d2 = s2 - lam_lo[j]; lam_lo[j] = s2; tot += d2; dj += d2 * Wm[j][j];
-          if (CHECK) { const real v = d2 * d2 - P.resid * di * di; worst = v > worst ? v : worst; }
-          real d3 = lrh[j] + dj * di, s3 = max_(lam_hi[j] + d3, (real)0);
-          d3 = s3 - lam_hi[j]; lam_hi[j] = s3; tot -= d3;
-          if (CHECK) { const real v = d3 * d3 - P.resid * di * di; worst = v > worst ? v : worst; }
-  #pragma unroll
-          for (int k = 0; k < NJ; k++) du[k] += Wm[j][k] * tot;
-        }
+        for (int k = 0; k < NJ; k++) du[k] += Wm[j][k] * tot;
+      };
+      joint_rows(std::integral_constant<int, 0>{}); joint_rows(std::integral_constant<int, 1>{}); joint_rows(std::integral_constant<int, 2>{});
+      joint_rows(std::integral_constant<int, 3>{}); joint_rows(std::integral_constant<int, 4>{}); joint_rows(std::integral_constant<int, 5>{});
         // Contact rows.  The whole 24-word record of a contact is read in ONE batch and pinned in registers before any of it is used: left
         // to the compiler (at the register limit) the loop read two words, waited, used them, read the next two -- twelve LDS round trips
         // per contact, 4 - 6 k cycles per PGS iteration for a wave whose lanes have up to six contacts (profiles/r04_fly_trace.txt).  And
@@ -529,38 +564,13 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         }
       return worst;
     };
-    // The same sweep with one env per quad.  du3: this lane's three components of du; Wq[j]: its three entries of motor column j (zero in
-    // the two object lanes).  Row j needs du[j] from its owner (one quad_perm broadcast); the row's scalar arithmetic is replicated, so
-    // `worst` -- and with it the exit decision -- is identical in the four lanes.
-    real du3[3] = {0, 0, 0}, Wq[NJ][3], wjj[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      wjj[j] = Wm[j][j];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        if constexpr (Q::QUAD) Wq[j][k] = quad.lane4() == 0 ? Wm[j][k] : quad.lane4() == 1 ? Wm[j][3 + k] : (real)0;
-        else Wq[j][k] = 0;
-      }
-    }
     auto sweep_quad = [&](auto CHECKTAG) __attribute__((always_inline)) -> real {
       constexpr bool CHECK = decltype(CHECKTAG)::value;
       real worst = -1;
       if constexpr (Q::QUAD) {
         auto joint_rows = [&](auto JTAG) __attribute__((always_inline)) {
           constexpr int j = decltype(JTAG)::value;
-          const real lim = U_EFFORT[j] * dt, di = mdi[j];
-          const real duj = quad.template bcast<(j / 3)>(du3[j % 3]);
-          real dl = mrhs[j] - duj * di, sum = med3_(lam_m[j] + dl, -lim, lim);
-          dl = sum - lam_m[j]; lam_m[j] = sum;
-          real tot = dl;
-          if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
-          real dj = duj + dl * wjj[j];
-          real d2 = lrl[j] - dj * di, s2 = max_(lam_lo[j] + d2, (real)0);
-          d2 = s2 - lam_lo[j]; lam_lo[j] = s2; tot += d2; dj += d2 * wjj[j];
-          if (CHECK) { const real v = d2 * d2 - P.resid * di * di; worst = v > worst ? v : worst; }
-          real d3 = lrh[j] + dj * di, s3 = max_(lam_hi[j] + d3, (real)0);
-          d3 = s3 - lam_hi[j]; lam_hi[j] = s3; tot -= d3;
-          if (CHECK) { const real v = d3 * d3 - P.resid * di * di; worst = v > worst ? v : worst; }
+          const real tot = joint_tot(JTAG, quad.template bcast<(j / 3)>(du3[j % 3]), CHECKTAG, worst);
   #pragma unroll
           for (int k = 0; k < 3; k++) du3[k] += Wq[j][k] * tot;
         };
@@ -600,18 +610,42 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       }
       return worst;
     };
-    int it = 0;
-    for (; it < P.iters; it++) {
-      const int i1 = it + 1;
-      const bool chk = P.checkstride <= 1 || i1 <= 4 || i1 == P.iters || (i1 - 4) % P.checkstride == 0;
+    auto one = [&](bool chk) __attribute__((always_inline)) -> bool {
+      if constexpr (Q::QUAD) return chk ? sweep_quad(std::true_type{}) <= 0 : (sweep_quad(std::false_type{}), false);
+      else return chk ? sweep(std::true_type{}) <= 0 : (sweep(std::false_type{}), false);
+    };
+    int it = 0; const int limmask0 = limmask; bool redone = false;
+#pragma nounroll
+    for (int pass = 0; pass < 2; pass++) {
+      if (pass == 1) {
+        if (!(viol > 0)) break;              // (per env: the envs whose skipped rows stayed no-ops keep their pass-0 result)
+        limmask = (1 << NJ) - 1; redone = true;
+      }
+#pragma unroll
+      for (int i = 0; i < FND; i++) du[i] = 0;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) { lam_m[j] = 0; lam_lo[j] = 0; lam_hi[j] = 0; }
+      du3[0] = du3[1] = du3[2] = 0; viol = -1;
       if constexpr (Q::QUAD) {
-        if (chk) { if (sweep_quad(std::true_type{}) <= 0) { it++; break; } }
-        else sweep_quad(std::false_type{});
-      } else {
-        if (chk) { if (sweep(std::true_type{}) <= 0) { it++; break; } }
-        else sweep(std::false_type{});
+#pragma unroll
+        for (int c = 0; c < KR; c++) lamr[c] = 0;
+      }
+      if (pass == 1) for (int c = 0; c < nc; c++) mem.at(c * RW + RW - 1) = 0;
+      // iterations 1 .. 4 with the test, then groups of `checkstride`: stride - 1 without, one with; the last iteration always with (the
+      // structure of pgs_iteration_loop, pih_wave.h: no per-iteration modulo -- as `(i - 4) % stride` it was a 40-instruction integer
+      // division in front of every sweep)
+      it = 0;
+      const int iters = P.iters, stride = P.checkstride, lead = stride <= 1 ? iters : 4;
+      bool conv = false;
+      while (!conv && it < iters && it < lead) { it++; conv = one(true); }
+      while (!conv && it < iters) {
+        const int stop = it + stride - 1 < iters - 1 ? it + stride - 1 : iters - 1;
+#pragma nounroll
+        while (it < stop) { it++; one(false); }
+        it++; conv = one(true);
       }
     }
+    if (dbg && P.debug) dbg[14] = redone ? (real)2 : (real)(limmask0 != 0);      // 1: limit rows of some joint from the start; 2: the solve was repeated with every limit row
     if constexpr (Q::QUAD) {
 #pragma unroll
       for (int c = 0; c < KR; c++) if (c < nc) mem.at(c * CWQ + 8) = lamr[c];

@@ -354,6 +354,13 @@ struct MailboxIk {
 };
 // QUAD: one env per quad of lanes (pih_fly.h): a step wavefront holds 16 envs, the PGS sweep is split over the quad; the controller
 // wavefronts stay one env per lane, so one flag covers four step wavefronts.
+__device__ __forceinline__ int fly_wave_or(int x) {     // OR of a 6-bit mask over the wavefront's active lanes, as a scalar
+  int m = 0;
+#pragma unroll
+  for (int k = 0; k < fly::NJ; k++) if (__builtin_amdgcn_ballot_w64((x >> k) & 1) != 0) m |= 1 << k;
+  return __builtin_amdgcn_readfirstlane(m);
+}
+struct FlyLane : fly::NoQuad { __device__ __forceinline__ int wave_or(int x) const { return fly_wave_or(x); } };
 struct FlyQuad : QuadDpp {
   static constexpr bool QUAD = true;
   __device__ __forceinline__ int wave_max(int x) const {     // the largest x of the wavefront's active lanes (0 <= x <= fly::NC), as a scalar
@@ -362,6 +369,7 @@ struct FlyQuad : QuadDpp {
     for (int k = 1; k <= fly::NC; k++) if (__builtin_amdgcn_ballot_w64(x >= k) != 0) m = k;
     return __builtin_amdgcn_readfirstlane(m);
   }
+  __device__ __forceinline__ int wave_or(int x) const { return fly_wave_or(x); }
 };
 template <int MODE, bool QUAD = false>
 __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
@@ -412,9 +420,9 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
   if constexpr (MODE == 2) {
     MailboxIk mb; mb.flag = F.flags + (env >> 6); mb.mail = F.mail; mb.err = F.err; mb.epoch = F.epoch; mb.env = env; mb.n = n;
     if constexpr (QUAD) { FlyQuad qd; qd.l = threadIdx.x & 3; fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, mb, qd); }
-    else fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, mb);
-  } else if constexpr (MODE == 1) fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::RecordIk());
-  else fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::InlineIk());
+    else fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, mb, FlyLane());
+  } else if constexpr (MODE == 1) fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::RecordIk(), FlyLane());
+  else fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::InlineIk(), FlyLane());
   if (writer) {
 #pragma unroll
     for (int w = 0; w < fly::SW; w++) state[(size_t)w * n + env] = S[w];

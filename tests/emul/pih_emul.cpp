@@ -47,7 +47,7 @@ struct QuadHost {
   real xor1(real x) const { return from(x, l ^ 1); }
   real xor2(real x) const { return from(x, l ^ 2); }
 };
-struct FlyQuadHost : QuadHost { static constexpr bool QUAD = true; int wave_max(int x) const { return x; } };
+struct FlyQuadHost : QuadHost { static constexpr bool QUAD = true; int wave_max(int x) const { return x; } int wave_or(int x) const { return x; } };
 template <class C> static void ikq_host(const pih_config* c, const double* q0, const double* tpos, const double* tquat, double* qout, double* ee_out) {
   const Params P = make_params(c);
   QuadShared sh;

@@ -358,3 +358,39 @@ def test_fly_quad_layout_more_contacts_than_register_records(oracle_mod):
         assert np.abs(sa[:, :31] - sb[:, :31]).max() < 1e-9 and np.abs(so[:, :31] - sb[:, :31]).max() < 1e-6
         assert np.abs(sa[:, 43] - sb[:, 43]).max() < 1e-6 * (1 + np.abs(sa[:, 43]).max())         # the summed normal force
     assert big >= 30
+
+
+def test_fly_limit_rows_speculation_is_exact(oracle_mod):
+    """The joint-limit rows are skipped for joints farther than 0.5 rad from their limits and the skipped rows' right-hand sides verified;
+    a violated one repeats the env's solve with every row (pih_fly.h).  Cases: (a) joints inside the 0.5-rad band (all rows from the
+    start, debug word 14 = 1), (b) joints 0.6 rad away running at 80 rad/s into the limit (the verification fires: 2), (c) far away (0):
+    both layouts of the host build against the oracle, which always sweeps all rows."""
+    O = oracle_mod
+    n = 12
+    kw = dict(seed=2, dt=DT, auto_reset=0, max_episode_steps=100000, exit_check_stride=16)
+    o = O.FlyOracle(n, **kw); a = E.EmulFly(n, "f64", debug=1, **kw); b = E.EmulFly(n, "f64", debug=1, **kw)
+    s = o.get_state()
+    lo = np.full(6, -np.pi); hi = -lo                                           # (ur5.urdf joint limits, include/pih_model.h PIH_UR5_LO / HI)
+    for e in range(n):
+        j = e % 6
+        if e < 4:   s[e, j] = hi[j] - 0.2; s[e, 6 + j] = 3.0                     # (a) inside the band, moving into the limit
+        elif e < 8: s[e, 2] = lo[2] + 0.51 + 0.01 * (e - 4); s[e, 8] = -85.0           # (b) the elbow outside the band, reaches the limit within the step
+        else:       s[e, 6 + j] = 5.0                                            # (c) at the rest pose
+    seen = set()
+    for t in range(4):
+        o.set_state(s); a.set_state(s); b.set_state(s)
+        act = np.zeros((n, 6)); act[:, :3] = [0.3, 0.1, 0.4]
+        o.step(act); a.step(act); _, _, _, bad = b.step_quad(act)
+        assert bad == 0
+        da, db = a.get_debug(), b.get_debug()
+        np.testing.assert_array_equal(da[:, 14], db[:, 14]); np.testing.assert_array_equal(da[:, 13], db[:, 13])
+        if t == 0:
+            assert (da[:4, 14] == 1).all() and (da[4:8, 14] == 2).all() and (da[8:, 14] == 0).all()
+        seen |= set(da[:, 14].astype(int).tolist())
+        sa, sb, so = a.get_state(), b.get_state(), o.get_state()
+        assert np.abs(sa[:, :31] - so[:, :31]).max() < 1e-9 * 100 and np.abs(sb[:, :31] - so[:, :31]).max() < 1e-9 * 100     # (velocities up to 100 rad/s)
+        np.testing.assert_array_equal(a.get_debug()[:, 13], o.pgs_iters())
+        s = so
+    assert seen == {0, 1, 2}
+    # the limit did hold: no joint beyond its limit by more than the one-step overshoot the ERP removes
+    assert (s[:8, :6] <= hi + 0.05).all() and (s[:8, :6] >= lo - 0.05).all()
