@@ -48,6 +48,7 @@ struct NoQuad {                   // (the members are never called: they keep th
   PIH_HD real xor2(real x) const { return x; }
   PIH_HD int wave_max(int x) const { return x; }
   PIH_HD int wave_or(int x) const { return x; }
+  PIH_HD bool wave_any(bool x) const { return x; }
 };
 
 PIH_CONST real U_MASS[NJ] = PIH_UR5_MASS;
@@ -480,12 +481,12 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
     // runs, and the two right-hand sides the skipped rows would have seen are tracked (`viol`, exactly the expressions of the full rows,
     // off the dependent chain).  If one of them ever turns positive the skipped row would have acted: that env's solve is discarded and
     // repeated with all rows (pass 1).  Results are those of the full sweep, bit for bit, either way.
-    constexpr real LIMIT_REACH = (real)0.5;            // [rad]: 60 rad/s for one step of 1/120 s
+    constexpr real LIMIT_REACH = (real)0.25;           // [rad]: 30 rad/s for one step of 1/120 s (random-action rollouts stay below 20)
     int limmask = 0;
 #pragma unroll
     for (int j = 0; j < NJ; j++) if (q[j] - U_LO[j] < LIMIT_REACH || U_HI[j] - q[j] < LIMIT_REACH) limmask |= 1 << j;
-    limmask = quad.wave_or(limmask);
-    real viol = -1;
+    limmask = P.nospec ? (1 << NJ) - 1 : quad.wave_or(limmask);      // (pih_config.schedule + 64: every limit row, always -- A/B switch)
+    real viol = -1, vlo[NJ], vhi[NJ];
     // the three rows of joint j given du[j]; returns the joint's total impulse change
     auto joint_tot = [&](auto JTAG, real duj, auto CHECKTAG, real& worst) __attribute__((always_inline)) -> real {
       constexpr int j = decltype(JTAG)::value;
@@ -494,19 +495,20 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       real dl = mrhs[j] - duj * di, sum = med3_(lam_m[j] + dl, -lim, lim);
       dl = sum - lam_m[j]; lam_m[j] = sum;
       if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
-      real dj = duj + dl * wjj[j];
-      if (!((limmask >> j) & 1)) {                     // (wave-uniform)
-        const real r2 = lrl[j] - dj * di, r3 = lrh[j] + dj * di;
-        viol = max_(viol, max_(r2, r3));
-        return dl;
+      real dj = duj + dl * wjj[j], tot = dl;
+      // verification of a skipped joint: its limit rows are no-ops as long as  vlo[j] < dj < vhi[j]  (the rows' right-hand sides lrl - dj di
+      // and lrh + dj di solved for dj, with a 1e-5 safety margin on the conservative side; -BIG / +BIG for a joint that runs its rows)
+      viol = max_(viol, max_(vlo[j] - dj, dj - vhi[j]));
+      // (wave-uniform; `unlikely` moves the block out of line: the skipped block costs the fall-through path nothing)
+      if (__builtin_expect(((limmask >> j) & 1) != 0, 0)) {
+        const real r2 = lrl[j] - dj * di;
+        real s2 = max_(lam_lo[j] + r2, (real)0);
+        const real d2 = s2 - lam_lo[j]; lam_lo[j] = s2; tot += d2; dj += d2 * wjj[j];
+        if (CHECK) { const real v = d2 * d2 - P.resid * di * di; worst = v > worst ? v : worst; }
+        real d3 = lrh[j] + dj * di, s3 = max_(lam_hi[j] + d3, (real)0);
+        d3 = s3 - lam_hi[j]; lam_hi[j] = s3; tot -= d3;
+        if (CHECK) { const real v = d3 * d3 - P.resid * di * di; worst = v > worst ? v : worst; }
       }
-      real tot = dl;
-      real d2 = lrl[j] - dj * di, s2 = max_(lam_lo[j] + d2, (real)0);
-      d2 = s2 - lam_lo[j]; lam_lo[j] = s2; tot += d2; dj += d2 * wjj[j];
-      if (CHECK) { const real v = d2 * d2 - P.resid * di * di; worst = v > worst ? v : worst; }
-      real d3 = lrh[j] + dj * di, s3 = max_(lam_hi[j] + d3, (real)0);
-      d3 = s3 - lam_hi[j]; lam_hi[j] = s3; tot -= d3;
-      if (CHECK) { const real v = d3 * d3 - P.resid * di * di; worst = v > worst ? v : worst; }
       return tot;
     };
     // One sweep over the rows; CHECK: also Bullet's exit test -- the largest squared row residual against residual_threshold.  The test
@@ -578,7 +580,8 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
         joint_rows(std::integral_constant<int, 3>{}); joint_rows(std::integral_constant<int, 4>{}); joint_rows(std::integral_constant<int, 5>{});
   #pragma unroll
         for (int c = 0; c < KR; c++) {
-          if (c < ncw) {                     // (wave-uniform)
+          if (c >= ncw) break;               // (wave-uniform: ONE taken branch per sweep, past the remaining register records)
+          {
             real jd = Rr[c][0] * du3[0] + Rr[c][1] * du3[1] + Rr[c][2] * du3[2];
             jd += quad.xor1(jd); jd += quad.xor2(jd);
             const real di = Rr[c][6];
@@ -618,8 +621,17 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
 #pragma nounroll
     for (int pass = 0; pass < 2; pass++) {
       if (pass == 1) {
-        if (!(viol > 0)) break;              // (per env: the envs whose skipped rows stayed no-ops keep their pass-0 result)
+        // (wave-uniform: every env of the wavefront repeats the solve -- those whose skipped rows stayed no-ops arrive at their pass-0
+        //  result again, bit for bit: that is what the verification establishes)
+        if (!quad.wave_any(viol > 0)) break;
         limmask = (1 << NJ) - 1; redone = true;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const real a = lrl[j] * wjj[j], b = -lrh[j] * wjj[j];
+        const bool full = ((limmask >> j) & 1) != 0;
+        vlo[j] = full ? -(real)PIH_BIG : a + ((real)1e-5 * absr(a) + (real)1e-12);
+        vhi[j] = full ? (real)PIH_BIG : b - ((real)1e-5 * absr(b) + (real)1e-12);
       }
 #pragma unroll
       for (int i = 0; i < FND; i++) du[i] = 0;

@@ -360,7 +360,10 @@ __device__ __forceinline__ int fly_wave_or(int x) {     // OR of a 6-bit mask ov
   for (int k = 0; k < fly::NJ; k++) if (__builtin_amdgcn_ballot_w64((x >> k) & 1) != 0) m |= 1 << k;
   return __builtin_amdgcn_readfirstlane(m);
 }
-struct FlyLane : fly::NoQuad { __device__ __forceinline__ int wave_or(int x) const { return fly_wave_or(x); } };
+struct FlyLane : fly::NoQuad {
+  __device__ __forceinline__ int wave_or(int x) const { return fly_wave_or(x); }
+  __device__ __forceinline__ bool wave_any(bool x) const { return __builtin_amdgcn_ballot_w64(x) != 0; }
+};
 struct FlyQuad : QuadDpp {
   static constexpr bool QUAD = true;
   __device__ __forceinline__ int wave_max(int x) const {     // the largest x of the wavefront's active lanes (0 <= x <= fly::NC), as a scalar
@@ -370,6 +373,7 @@ struct FlyQuad : QuadDpp {
     return __builtin_amdgcn_readfirstlane(m);
   }
   __device__ __forceinline__ int wave_or(int x) const { return fly_wave_or(x); }
+  __device__ __forceinline__ bool wave_any(bool x) const { return __builtin_amdgcn_ballot_w64(x) != 0; }
 };
 template <int MODE, bool QUAD = false>
 __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __restrict__ state, const float* __restrict__ actions,
@@ -552,7 +556,7 @@ static Params make_params(const pih_config* c) {
   P.dt = c->dt; P.resid = c->residual_threshold; P.erp = c->erp; P.warm = c->warmstart; P.margin = c->contact_margin;
   P.slop = c->linear_slop; P.ikdamp = c->ik_damping; P.ikres = c->ik_residual; P.dv = c->dv; P.iters = c->solver_iters;
   P.ikiters = c->ik_iters; P.mode = c->mode; P.maxsteps = c->max_episode_steps; P.autoreset = c->auto_reset;
-  P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball; P.noprio = (c->schedule & 4) != 0;
+  P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball; P.noprio = (c->schedule & 4) != 0; P.nospec = (c->schedule & 64) != 0;
   P.checkstride = c->exit_check_stride < 1 ? 1 : c->exit_check_stride;
   P.object = c->object_id;
   return P;

@@ -361,9 +361,9 @@ def test_fly_quad_layout_more_contacts_than_register_records(oracle_mod):
 
 
 def test_fly_limit_rows_speculation_is_exact(oracle_mod):
-    """The joint-limit rows are skipped for joints farther than 0.5 rad from their limits and the skipped rows' right-hand sides verified;
-    a violated one repeats the env's solve with every row (pih_fly.h).  Cases: (a) joints inside the 0.5-rad band (all rows from the
-    start, debug word 14 = 1), (b) joints 0.6 rad away running at 80 rad/s into the limit (the verification fires: 2), (c) far away (0):
+    """The joint-limit rows are skipped for joints farther than 0.25 rad from their limits and the skipped rows' right-hand sides verified;
+    a violated one repeats the env's solve with every row (pih_fly.h).  Cases: (a) joints inside the 0.25-rad band (all rows from the
+    start, debug word 14 = 1), (b) joints 0.26 .. 0.29 rad away running at 60 rad/s into the limit (the verification fires: 2), (c) far away (0):
     both layouts of the host build against the oracle, which always sweeps all rows."""
     O = oracle_mod
     n = 12
@@ -374,7 +374,7 @@ def test_fly_limit_rows_speculation_is_exact(oracle_mod):
     for e in range(n):
         j = e % 6
         if e < 4:   s[e, j] = hi[j] - 0.2; s[e, 6 + j] = 3.0                     # (a) inside the band, moving into the limit
-        elif e < 8: s[e, 2] = lo[2] + 0.51 + 0.01 * (e - 4); s[e, 8] = -85.0           # (b) the elbow outside the band, reaches the limit within the step
+        elif e < 8: s[e, 2] = lo[2] + 0.26 + 0.01 * (e - 4); s[e, 8] = -60.0           # (b) the elbow outside the band, reaches the limit within the step
         else:       s[e, 6 + j] = 5.0                                            # (c) at the rest pose
     seen = set()
     for t in range(4):

@@ -263,6 +263,38 @@ def test_fly_quad_layout_more_contacts_than_register_records(torch_mod, oracle_m
     assert np.percentile(eo, 50) < 2e-5 and np.percentile(eo, 99) < 2e-3 and np.percentile(el, 99) < 2e-3
 
 
+@pytest.mark.parametrize("sched", [1, 1 + 32])
+def test_fly_limit_rows_speculation_is_exact(torch_mod, oracle_mod, sched):
+    """The joint-limit rows of joints farther than 0.25 rad from their limits (in every env of the wavefront) are skipped and verified; a
+    violated verification repeats the wavefront's solve with every row (pih_fly.h).  96 envs = 6 step wavefronts of the quad layout
+    (sched 1; 2 of the lane layout, sched 33): wavefronts 0-1 joints inside the band (debug word 14 = 1), 2-3 the elbow 0.26 .. 0.28 rad
+    away at -60 rad/s (reaches the limit within the step: 2 in the envs that do and in their wavefront neighbours), 4-5 at rest (0);
+    state against the oracle, which always sweeps every row, and iteration counts equal."""
+    torch = torch_mod
+    n = 96 if sched == 1 else 192
+    per = n // 3
+    kw = dict(seed=2, dt=DT, auto_reset=0, max_episode_steps=100000)
+    o = oracle_mod.FlyOracle(n, exit_check_stride=16, **kw)
+    g = _gpu(n, debug=1, schedule=sched, **kw)
+    s = o.get_state()
+    for e in range(n):
+        j = e % 6
+        if e < per:        s[e, j] = np.pi - 0.2; s[e, 6 + j] = 3.0
+        elif e < 2 * per and e % 4 == 0: s[e, 2] = -np.pi + 0.26 + 0.01 * (e % 3); s[e, 8] = -60.0
+        elif e >= 2 * per: s[e, 6 + j] = 5.0
+    act = np.zeros((n, 6)); act[:, :3] = [0.3, 0.1, 0.4]
+    for t in range(3):
+        o.set_state(s); g.set_state(torch.tensor(s, dtype=torch.float32))
+        o.step(act); g.step(torch.tensor(act, dtype=torch.float32))
+        d = g.debug().cpu().numpy(); so = o.get_state(); sg = g.state().cpu().numpy().astype(np.float64)
+        if t == 0:
+            assert (d[:per, 14] == 1).all() and (d[per:2 * per, 14] == 2).all() and (d[2 * per:, 14] == 0).all(), d[:, 14]
+        assert (d[:, 13] == o.pgs_iters()).mean() > 0.97
+        assert np.abs(sg[:, :6] - so[:, :6]).max() < 2e-4 and np.abs(sg[:, 6:12] - so[:, 6:12]).max() < 2e-2       # (velocities up to 100 rad/s in float)
+        s = so
+    assert (s[:, :6] <= np.pi + 0.05).all() and (s[:, :6] >= -np.pi - 0.05).all()
+
+
 def test_fly_defaults_exit_test_and_cadence(torch_mod, oracle_mod):
     """The random-fly step AT THE LIBRARY DEFAULTS (residual_threshold 1e-7, exit_check_stride 16: what bench.py --task random-fly runs): the
     PGS exit test is live, evaluated at the sampled cadence.  One-step resynchronised against the oracle at the SAME cadence: iteration
