@@ -38,7 +38,11 @@ constexpr int LANE_WORDS = NC * CW + NC * KW;
 // three Jacobian and three response entries.  A row's J . du is three multiply-adds plus a two-step quad all-reduce (DPP quad_perm: VALU
 // operand modifiers, no LDS), its update three multiply-adds: 12 VALU instructions and 9 LDS words per contact instead of 45 and 24.
 constexpr int CWQ = 9;             // words of a lane's share of one contact row: 0-2 J | 3-5 W | 6 dinv | 7 rhs | 8 lambda
-constexpr int LANE_WORDS_Q = NC * CWQ + NC * KW;
+// quad layout: the candidates ALIAS the row area, 16 words up and with the records' stride: record c <= k lies in [9 c, 9 c + 9), below
+// candidate k at [16 + 9 k, 24 + 9 k) -- the compacted records never catch up with the candidates still to be read.  38 KB per wave.
+constexpr int CANDQ0 = 16, KWQ = CWQ;
+constexpr int LANE_WORDS_Q = CANDQ0 + NC * KWQ;
+static_assert(KW <= KWQ && CANDQ0 + KWQ > CWQ + KW - 1 && 6 * NJ <= LANE_WORDS_Q, "candidate k must not be overwritten by record k");
 constexpr int KR = 8;              // quad layout: the records of the first KR contacts of an env stay in REGISTERS over the PGS iterations (72 per lane)
 struct NoQuad {                   // (the members are never called: they keep the discarded quad branches well-formed)
   static constexpr bool QUAD = false;
@@ -186,7 +190,8 @@ struct FlyStamp { FlyStamp(real*, bool) {} void operator()(int) {} };
 template <class Ctl = InlineIk, class Q = NoQuad, class Mem>
 PIH_HD void step_env(real* S, const Params& P, int env_global, const real* action, real* obs, real* reward, unsigned char* done, Mem mem, real* dbg, Ctl ctl = Ctl(), Q quad = Q()) {
   constexpr int RW = Q::QUAD ? CWQ : CW;          // words of a contact record in this lane's memory
-  constexpr int CANDQ = NC * RW;                  // candidates follow the (compacted) row records
+  constexpr int CANDQ = Q::QUAD ? CANDQ0 : NC * RW;        // lane layout: candidates follow the (compacted) row records
+  constexpr int KS = Q::QUAD ? KWQ : KW;                   // stride of the candidates
   const real dt = P.dt;
   const bool frozen = !P.autoreset && S[PIH_F_DONE] != 0;   // finished envs keep their last values (envs/base_env.py:62,66)
   bool landed = false;
@@ -374,7 +379,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       if (k < NS) { valid = clink[i] >= 0; la = clink[i]; n = cn[i]; p = cp[i]; depth = cdepth[i]; }
       else if (k < 2 * NS) { depth = sc[i].z - (real)PIH_TABLE_Z - srad[i]; valid = i < nsph && depth < P.margin; landed = landed || (i < nsph && depth < (real)0.002); la = -1; n = mk(0, 0, 1); p = mk(sc[i].x, sc[i].y, sc[i].z - srad[i] - (real)0.5 * depth); }
       else { depth = adepth[i]; valid = depth < P.margin; la = 1 + i; n = mk(0, 0, 1); p = apt[i]; }
-      const int b = CANDQ + k * KW;
+      const int b = CANDQ + k * KS;
       mem.at(b) = valid ? (real)(la + 2) : (real)0;
       mem.at(b + 1) = n.x; mem.at(b + 2) = n.y; mem.at(b + 3) = n.z; mem.at(b + 4) = p.x; mem.at(b + 5) = p.y; mem.at(b + 6) = p.z; mem.at(b + 7) = depth;
     }
@@ -385,7 +390,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
 #pragma nounroll
     for (int k = 0; k < NC; k++) {
       const bool armtab = k >= 2 * NS;
-      const int kb = CANDQ + k * KW;
+      const int kb = CANDQ + k * KS;
       const real tag = mem.at(kb);
       const bool valid = tag != (real)0;
       if (valid) {
@@ -481,7 +486,7 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
     // runs, and the two right-hand sides the skipped rows would have seen are tracked (`viol`, exactly the expressions of the full rows,
     // off the dependent chain).  If one of them ever turns positive the skipped row would have acted: that env's solve is discarded and
     // repeated with all rows (pass 1).  Results are those of the full sweep, bit for bit, either way.
-    constexpr real LIMIT_REACH = (real)0.25;           // [rad]: 30 rad/s for one step of 1/120 s (random-action rollouts stay below 20)
+    const real LIMIT_REACH = (real)0.25;               // [rad]: 30 rad/s for one step of 1/120 s (random-action rollouts stay below 20)
     int limmask = 0;
 #pragma unroll
     for (int j = 0; j < NJ; j++) if (q[j] - U_LO[j] < LIMIT_REACH || U_HI[j] - q[j] < LIMIT_REACH) limmask |= 1 << j;

@@ -337,7 +337,6 @@ __global__ void __launch_bounds__(256) pih_fly_pre_kernel(Params P, float* __res
 // sweeps, collision detection and all response rows, i.e. later than the 24 us the IK takes.  Every workgroup of the launch carries the
 // step's 120 KB of dynamic LDS, so the layout is used only while 2 G workgroups fit the chip's CUs at once (n <= 8192); bigger batches
 // run the IK inside the step wavefront (MODE 0).  MODE 1: targets from a pre-launch (pih_fly_pre_kernel; measurement switch).
-#define PIH_FLY_QUAD_MAX_ENVS 4096
 struct FlyFused { int G, epoch; float* mail; int* flags; int* err; };
 struct MailboxIk {
   const int* flag; const float* mail; int* err; int epoch, env, n;
@@ -426,6 +425,7 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
     if constexpr (QUAD) { FlyQuad qd; qd.l = threadIdx.x & 3; fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, mb, qd); }
     else fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, mb, FlyLane());
   } else if constexpr (MODE == 1) fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::RecordIk(), FlyLane());
+  else if constexpr (QUAD) { FlyQuad qd; qd.l = threadIdx.x & 3; fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::InlineIk(), qd); }
   else fly::step_env(S, P, P.env0 + env, a, o, &r, &d, mem, dbge, fly::InlineIk(), FlyLane());
   if (writer) {
 #pragma unroll
@@ -518,7 +518,7 @@ struct pih_handle {
   int* order = nullptr;     // longest-job-first block -> env map (block 0 of pih_pre_kernel; two-launch path)
   // fused launch (default for the peg-in-hole task): controller mailbox + group flags + error word, three rotating bin buffers of the
   // in-kernel dispatch order, the launch counter
-  bool fused = false;
+  bool fused = false, flyquad = false;     // flyquad: random-fly step wavefronts hold one env per quad of lanes
   float* mail = nullptr; int* flags = nullptr; int* errw = nullptr; volatile int* errw_host = nullptr; int* bins = nullptr; size_t bin_ints = 0; int epoch = 0;
   std::string err;
   int timing = 0;           // 0 off; k >= 1: every k-th step launch is bracketed by events (pih_set_timing)
@@ -631,12 +631,18 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS * 64 * sizeof(float))));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS_Q * 64 * sizeof(float))));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pih_fly_step_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fly::LANE_WORDS_Q * 64 * sizeof(float))));
     {
       // fused launch (controller wavefronts + step wavefronts in one grid) while both sets of workgroups -- each with the step's 120 KB of
       // LDS -- fit the chip's CUs at once; schedule + 8: IK inside the step wavefront, + 16: IK as a quad-per-env pre-launch (switches)
       int cus = 0; HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
       const int G = (cfg->n_envs + 63) / 64;
-      h->fused = (cfg->schedule & (8 | 16)) == 0 && 2 * G <= cus;
+      // One env per QUAD of lanes in the step wavefronts (38 KB of LDS: four workgroups per CU) unless schedule + 32; its fused launch needs
+      // the G controller workgroups and the ceil(n / 16) step workgroups resident together: 4 per CU (n <= 13 104 on 256 CUs); bigger
+      // batches run the IK inside the quad's step wavefront.  The lane layout (120 KB per workgroup) fuses while 2 G <= CUs.
+      h->flyquad = (cfg->schedule & (32 | 16)) == 0;
+      const bool nofuse = (cfg->schedule & (8 | 16)) != 0;
+      h->fused = !nofuse && (h->flyquad ? G + (cfg->n_envs + 15) / 16 <= 4 * cus : 2 * G <= cus);
       if (h->fused) {
         HIPCHK(h, hipMalloc(&h->mail, (size_t)cfg->n_envs * fly::NJ * sizeof(float)));
         HIPCHK(h, hipMemset(h->mail, 0, (size_t)cfg->n_envs * fly::NJ * sizeof(float)));
@@ -761,8 +767,7 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
       if (*h->errw_host) { h->err = CTRL_TIMEOUT_MSG; return -5; }
       FF.G = G; FF.epoch = ++h->epoch; FF.mail = h->mail; FF.flags = h->flags; FF.err = h->errw;
       if (t) HIPCHK(h, hipEventRecord(t->b, s));
-      // one env per QUAD while the chip has a CU slot per 16 envs (two 64 KB workgroups per CU); schedule + 32: one env per lane (A/B)
-      if (h->cfg.n_envs <= PIH_FLY_QUAD_MAX_ENVS && !(h->cfg.schedule & 32))
+      if (h->flyquad)
         hipLaunchKernelGGL((pih_fly_step_kernel<2, true>), dim3(G + (h->cfg.n_envs + 15) / 16), dim3(64), (size_t)fly::LANE_WORDS_Q * 64 * sizeof(float), s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
       else
         hipLaunchKernelGGL(pih_fly_step_kernel<2>, dim3(2 * G), dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
@@ -772,7 +777,10 @@ static int launch_step(pih_handle* h, const float* actions, float* obs, float* r
       hipLaunchKernelGGL(pih_fly_step_kernel<1>, dim3(G), dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
     } else {
       if (t) HIPCHK(h, hipEventRecord(t->b, s));
-      hipLaunchKernelGGL(pih_fly_step_kernel<0>, dim3(G), dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
+      if (h->flyquad)
+        hipLaunchKernelGGL((pih_fly_step_kernel<0, true>), dim3((h->cfg.n_envs + 15) / 16), dim3(64), (size_t)fly::LANE_WORDS_Q * 64 * sizeof(float), s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
+      else
+        hipLaunchKernelGGL(pih_fly_step_kernel<0>, dim3(G), dim3(64), lds, s, h->P, h->state, actions, obs, reward, done, h->dbg, h->cfg.n_envs, FF);
     }
     if (t) HIPCHK(h, hipEventRecord(t->c, s));
     HIPCHK(h, hipGetLastError());

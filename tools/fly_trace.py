@@ -10,7 +10,7 @@ from peg_in_hole_gym_amd.vec_env import PihVecEnv  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 sched = int(sys.argv[2]) if len(sys.argv) > 2 else 1            # 33: one env per lane at every size
-EPW = 16 if (n <= 4096 and not sched & 32) else 64            # envs per step wavefront (one env per quad of lanes up to 4096 envs)
+EPW = 64 if sched & (32 | 16) else 16            # envs per step wavefront (one env per quad of lanes up to 4096 envs)
 env = PihVecEnv(n, auto_reset=1, debug=2, schedule=sched, task_id=1, dt=1 / 120.0, max_episode_steps=480, contact_margin=0.02)
 gen = torch.Generator(device="cuda").manual_seed(1234)
 a = torch.rand(64, n, 6, device="cuda", generator=gen) * 2 - 1

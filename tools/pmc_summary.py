@@ -28,7 +28,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         try:
             bj = json.loads(open(os.path.join(root, "gpurun_out", "pmc_%s%s_%s.bench.json" % (tag, suf, c))).read().strip().splitlines()[-1])
             n = int(bj["config"]["envs_per_gpu"]); g = (n + 63) // 64
-            if out["n_envs"] in (n, n + g, 2 * 64 * g, 64 * g):
+            # (random-fly up to 4096 envs: one env per QUAD of lanes in the step wavefronts: 64 x (g + ceil(n / 16)) lanes)
+            if out["n_envs"] in (n, n + g, 2 * 64 * g, 64 * g, 64 * (g + (n + 15) // 16)):
                 out["launch_units"] = out["n_envs"]; out["n_envs"] = n
         except Exception:  # noqa: BLE001
             pass
