@@ -136,7 +136,13 @@ __global__ void __launch_bounds__(64, 2) pih_step_kernel(Params P, float* __rest
         for (int i = 0; i < 13; i++) __hip_atomic_store(m + i, ov[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the mailbox stores of all 64 lanes are acknowledged ...
+    // The mailbox stores of all 64 lanes are acknowledged before the group is published: an explicit  s_waitcnt vmcnt(0).  The
+    // workgroup-scope release fence alone compiles to NO wait (the waves of a workgroup share their CU's L1, so the memory model needs none
+    // for that scope), and the flag store then overtook mailbox stores still in flight -- with 640+ workgroups in a random-fly launch a
+    // step wavefront read one stale target word in ~ 1 of 200 groups (tests/test_gpu_fly.py, 12 000 envs); an agent-scope release would
+    // add an L2 write-back (+ 50 us per step, section 6.0 of DESIGN.md) that write-through stores do not need.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (lane == 0) __hip_atomic_store(F.flags + blockIdx.x, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the group is published
     return;
@@ -348,7 +354,7 @@ struct MailboxIk {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-    for (int i = 0; i < fly::NJ; i++) qs[i] = __hip_atomic_load(mail + (size_t)i * n + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < fly::NJ; i++) qs[i] = __hip_atomic_load(mail + ((size_t)(env >> 6) * fly::NJ + i) * 64 + (env & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 };
 // QUAD: one env per quad of lanes (pih_fly.h): a step wavefront holds 16 envs, the PGS sweep is split over the quad; the controller
@@ -393,9 +399,10 @@ __global__ void __launch_bounds__(64, 1) pih_fly_step_kernel(Params P, float* __
       for (int k = 0; k < PIH_FLY_ACTION_DIM; k++) a[k] = actions[(size_t)env * PIH_FLY_ACTION_DIM + k];
       fly::InlineIk()(q, S3, a, P, qs);
 #pragma unroll
-      for (int i = 0; i < fly::NJ; i++) __hip_atomic_store(F.mail + (size_t)i * n + env, qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < fly::NJ; i++) __hip_atomic_store(F.mail + ((size_t)blockIdx.x * fly::NJ + i) * 64 + threadIdx.x, qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (see the peg-in-hole controller role: the stores are acknowledged before the flag)
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(F.flags + blockIdx.x, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
@@ -644,8 +651,9 @@ static int create_impl(pih_handle* h, const float* offsets_host, float** offd) {
       const bool nofuse = (cfg->schedule & (8 | 16)) != 0;
       h->fused = !nofuse && (h->flyquad ? G + (cfg->n_envs + 15) / 16 <= 4 * cus : 2 * G <= cus);
       if (h->fused) {
-        HIPCHK(h, hipMalloc(&h->mail, (size_t)cfg->n_envs * fly::NJ * sizeof(float)));
-        HIPCHK(h, hipMemset(h->mail, 0, (size_t)cfg->n_envs * fly::NJ * sizeof(float)));
+        // mailbox [group][word][64 lanes]: the two 128-byte lines of a (group, word) hold no other group's targets
+        HIPCHK(h, hipMalloc(&h->mail, (size_t)G * 64 * fly::NJ * sizeof(float)));
+        HIPCHK(h, hipMemset(h->mail, 0, (size_t)G * 64 * fly::NJ * sizeof(float)));
         HIPCHK(h, hipMalloc(&h->flags, (size_t)G * sizeof(int)));
         HIPCHK(h, hipMemset(h->flags, 0, (size_t)G * sizeof(int)));
         HIPCHK(h, hipHostMalloc((void**)&h->errw_host, sizeof(int), hipHostMallocMapped));

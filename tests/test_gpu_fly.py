@@ -187,7 +187,7 @@ def test_fused_fly_launch_equals_ik_inside_the_step_wavefront():
     while controller + step workgroups are resident together, n <= 13 104) and one env per lane (schedule + 32; fused up to 8 192 envs)."""
     import torch
     from peg_in_hole_gym_amd.vec_env import PihVecEnv
-    for n, lane in ((4096, 0), (12000, 0), (4096, 32), (10000, 32)):
+    for n, lane in ((4096, 0), (8192, 0), (12000, 0), (13000, 0), (4096, 32), (8192, 32), (10000, 32)):
         kw = dict(task_id=1, seed=3, dt=DT, auto_reset=1, max_episode_steps=60, contact_margin=0.02)
         a = PihVecEnv(n, schedule=1 + lane, **kw); b = PihVecEnv(n, schedule=1 + 8 + lane, **kw)
         gen = torch.Generator(device="cuda").manual_seed(9)
