@@ -429,8 +429,10 @@ def main():
                          "traffic": traffic, "traffic_detail": traffic_detail, "traffic_unit": "bytes per launch (algorithmic: %d)" % (alg_bytes * n),
                          "kernel": "pih_fly_step_kernel" if fly else "pih_step_kernel",
                          "launches_per_step": ("two: pih_fly_pre_kernel (IK, one env per quad of lanes) + pih_fly_step_kernel" if (args.schedule & 16) else
-                                               "one: pih_fly_step_kernel, IK inside the step wavefront" if (args.schedule & 8) or n > 8192 else
-                                               "one: pih_fly_step_kernel = IK controller wavefronts + step wavefronts (fused launch)") if fly else
+                                               ("one: pih_fly_step_kernel, step wavefronts with one env per LANE; IK %s" % ("inside the step wavefront" if (args.schedule & 8) or n > 8192 else "in controller wavefronts of the same launch"))
+                                               if (args.schedule & 32) else
+                                               ("one: pih_fly_step_kernel, step wavefronts with one env per QUAD of lanes (16 envs per wavefront, PGS sweep split over the quad); IK %s" % (
+                                                   "inside the step wavefront" if (args.schedule & 8) or n > 13104 else "in controller wavefronts (one env per lane) of the same launch"))) if fly else
                                               ("two: pih_pre_kernel (controller) + pih_step_kernel" if (args.schedule & 24) or (args.schedule & 3) == 2 else
                                                "one: pih_step_kernel = controller wavefronts + env wavefronts (fused launch); pre_kernel_avg_ms is the gap between two launches"),
                          "kernel_avg_ms": kernel_ms, "pre_kernel_avg_ms": pre_ms, "launches": launches, "event_stride": args.timing_stride,

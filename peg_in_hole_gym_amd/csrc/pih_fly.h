@@ -1,4 +1,5 @@
-// pih_fly.h -- the 'random-fly' task (BASELINE.json configs[4]; README.md:38): UR5 + one free-flying object, ONE ENV PER LANE.
+// pih_fly.h -- the 'random-fly' task (BASELINE.json configs[4]; README.md:38): UR5 + one free-flying object; one env per LANE or (the GPU
+// default since round 4) per QUAD of lanes.
 //
 // What replaces what (paths relative to /root/reference/peg_in_hole_gym/):
 //   controller        ur_execute: getQuaternionFromEuler + calculateInverseKinematics + setJointMotorControlArray(POSITION_CONTROL,
@@ -8,12 +9,14 @@
 // The task CLASS is not in the reference snapshot (TASK_LIST holds only 'peg-in-hole', envs/base_env.py:9-11): rest pose, launch
 // law, reward / done and the observation are BUILD-DEFINED (same definitions as oracle/pih_fly_oracle.c).
 //
-// Mapping: the system is 12 DOF (6 arm joints + a free rigid body) with at most 10 frictionless contacts -- far too little
-// parallel work for a wavefront per env -- and its dominant cost is the 20 strictly sequential 6x6 DLS solves of the IK.  So
-// one env is one LANE: 64 envs per wavefront, plain scalar code per lane, state in HBM as structure-of-arrays
-// [word][env] so that every load / store of a wave is one coalesced 256 B segment.  The rigid-body quantities of the six links
-// stay in registers; the per-contact solver rows (Jacobian, response, right-hand side) are staged in LDS, lane-major
+// Mapping: the system is 12 DOF (6 arm joints + a free rigid body) with at most 15 frictionless contacts -- far too little parallel work
+// for a wavefront per env.  The per-env code is plain scalar code per lane, state in HBM as structure-of-arrays [word][env]; the
+// rigid-body quantities of the six links stay in registers; contact candidates and solver rows are staged in LDS, lane-major
 // ([word][lane]: conflict-free, and a lane may index its rows dynamically without spilling to scratch).
+//   * one env per LANE (`NoQuad`; rounds 2-3, schedule + 32): 64 envs per wavefront;
+//   * one env per QUAD (`Q::QUAD`): 16 envs per wavefront; kinematics, dynamics and the row build run replicated in the quad's four lanes
+//     (a wavefront issues the same instructions whether 16 or 64 of its lanes hold distinct envs, and 4 x the wavefronts spread over 4 x
+//     the SIMDs), the PGS sweep -- 75 % of the step -- is split over the quad (see CWQ below).
 // Dynamics: articulated-body algorithm, world-aligned axes, link origin as reference point (as in pih_device.h), impulse
 // responses from the same articulated inertias; sequential-impulse PGS over (motor, lower limit, upper limit) per joint, then
 // the contact normals.  The oracle derives the same physics by RNEA + dense Cholesky.
@@ -481,11 +484,11 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
     }
     // SPECULATE AND VERIFY on the joint-limit rows.  A limit row whose multiplier is zero and whose right-hand side stays <= 0 is a no-op,
     // and that is every limit row of a joint that cannot reach its limit within this step -- but the three rows of a joint are one
-    // dependent chain (17 instructions; a lone wavefront waits ~ 8 cycles for each), 6 joints per sweep.  So: joints closer than
-    // LIMIT_REACH to a limit (in any env of the wavefront: `limmask`, wave-uniform) run all three rows; for the others only the motor row
-    // runs, and the two right-hand sides the skipped rows would have seen are tracked (`viol`, exactly the expressions of the full rows,
-    // off the dependent chain).  If one of them ever turns positive the skipped row would have acted: that env's solve is discarded and
-    // repeated with all rows (pass 1).  Results are those of the full sweep, bit for bit, either way.
+    // dependent chain (17 instructions), 6 joints per sweep.  So: joints closer than LIMIT_REACH to a limit (in any env of the wavefront:
+    // `limmask`, wave-uniform) run all three rows; for the others only the motor row runs, and the joint velocity the skipped rows would
+    // have seen is checked against the band in which both are no-ops (`viol`, off the dependent chain, with a safety margin).  If it ever
+    // leaves the band the skipped row might have acted: the wavefront's solve is discarded and repeated with all rows (pass 1).  Results
+    // are those of the full sweep, bit for bit, either way (tools/fly_pgs_cost.py: 1 210 -> 690 cycles per sweep of the joint rows).
     const real LIMIT_REACH = (real)0.25;               // [rad]: 30 rad/s for one step of 1/120 s (random-action rollouts stay below 20)
     int limmask = 0;
 #pragma unroll

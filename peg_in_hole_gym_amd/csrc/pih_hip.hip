@@ -311,12 +311,11 @@ __global__ void pih_gather_kernel(const float* __restrict__ state, float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ 'random-fly' task kernels
-// One env per LANE (pih_fly.h).  state: float[PIH_FLY_STATE_WORDS][n] (structure-of-arrays: word w of the 64 envs of a wave is
-// one coalesced 256 B segment).  LDS: the per-lane contact rows, [word][lane] (92 KB per wave: one wave per CU; the kernel needs
-// 454 registers, i.e. one wave per SIMD, anyway).
-// (Measured on the MI355X, round 3, profiles/r03_fly_envs_per_wave.txt: packing FEWER envs into a wave -- 32 .. 4, i.e. 128 .. 1024
-//  waves for 4096 envs -- does not shorten the launch although the data-dependent PGS loop then waits for the slowest of fewer lanes,
-//  and from 512 waves on it lengthens it: the waves of a CU pair then contend for instruction fetch, SQ_WAIT_INST_ANY 2 % -> 52 %.)
+// One env per LANE or per QUAD of lanes (pih_fly.h).  state: float[PIH_FLY_STATE_WORDS][n] (structure-of-arrays: word w of the envs of a
+// wave is one coalesced segment).  LDS: the per-lane contact rows, [word][lane]: 120 KB per wave in the lane layout (one wave per CU), 38 KB
+// in the quad layout (four per CU; the kernel needs 450 registers, i.e. one wave per SIMD, anyway).
+// (Round 3, profiles/r03_fly_envs_per_wave.txt: packing FEWER envs into a wave of the lane layout did not shorten the launch, and with 120 KB
+//  of LDS per wave it cost rounds.  The quad layout does not idle the other lanes: it gives them a share of the PGS sweep.)
 // Launch 1 of a random-fly step: the controller ur_execute (envs/utils.py:70-82) -- getQuaternionFromEuler + calculateInverseKinematics --
 // with one env per QUAD of lanes (pih_ikq.h); writes the IK targets into the state record (words PIH_F_TARGET .., structure-of-arrays).
 // 256 threads = 64 envs per block.  (Rounds 2-3 ran the IK inside the one-env-per-lane step kernel, where it was 60 % of the
@@ -338,11 +337,12 @@ __global__ void __launch_bounds__(256) pih_fly_pre_kernel(Params P, float* __res
 }
 
 // The fused random-fly launch (round 4, as the peg-in-hole one): the first G = ceil(n / 64) blocks are CONTROLLER wavefronts (the IK of 64
-// envs, one per lane, straight into a structure-of-arrays mailbox, then the epoch into the block's flag), the next G blocks the step
-// wavefronts, whose lanes read their targets from the mailbox right before the PGS loop -- after forward kinematics, the articulated-body
-// sweeps, collision detection and all response rows, i.e. later than the 24 us the IK takes.  Every workgroup of the launch carries the
-// step's 120 KB of dynamic LDS, so the layout is used only while 2 G workgroups fit the chip's CUs at once (n <= 8192); bigger batches
-// run the IK inside the step wavefront (MODE 0).  MODE 1: targets from a pre-launch (pih_fly_pre_kernel; measurement switch).
+// envs, one per lane, straight into a mailbox [group][word][lane], then the epoch into the block's flag), the following blocks the step
+// wavefronts (ceil(n / 16) in the quad layout, G in the lane layout), whose lanes read their targets from the mailbox right before the PGS
+// loop -- after forward kinematics, the articulated-body sweeps, collision detection and all response rows.  Every workgroup of the launch
+// carries the step's dynamic LDS, and a step wavefront spins on its controller's flag, so the layout is used only while ALL workgroups are
+// resident at once (pih_create: quad layout 4 per CU, lane layout 1 per CU); bigger batches run the IK inside the step wavefront (MODE 0).
+// MODE 1: targets from a pre-launch (pih_fly_pre_kernel; measurement switch).
 struct FlyFused { int G, epoch; float* mail; int* flags; int* err; };
 struct MailboxIk {
   const int* flag; const float* mail; int* err; int epoch, env, n;

@@ -54,6 +54,14 @@ elif [ "$PART" = "b" ]; then
   timeout -k 10 300 python tools/iter_cost.py > $O/iter_cost_$TAG.txt 2>&1; cat $O/iter_cost_$TAG.txt | tail -12
   timeout -k 10 300 python tools/sched_trace.py 4096 > $O/sched_trace_$TAG.txt 2>&1; head -8 $O/sched_trace_$TAG.txt
   timeout -k 10 300 python tools/ik_bench.py > $O/ik_bench_$TAG.txt 2>&1; grep -v amdgpu.ids $O/ik_bench_$TAG.txt
+  timeout -k 10 200 python tools/fly_trace.py 4096 > $O/fly_trace_$TAG.txt 2>&1; grep -A2 "launch 1" $O/fly_trace_$TAG.txt | cut -c1-700
+  timeout -k 10 200 python tools/fly_trace.py 4096 33 > $O/fly_trace_lane_$TAG.txt 2>&1; grep -A2 "launch 1" $O/fly_trace_lane_$TAG.txt | cut -c1-700
+  timeout -k 10 200 python tools/fly_pgs_cost.py > $O/fly_pgs_cost_$TAG.txt 2>&1; grep -v amdgpu.ids $O/fly_pgs_cost_$TAG.txt | cut -c1-330
+  for cfg in "fly_lane:--task random-fly --no-cpu-baseline --schedule 33" "fly_all_limit_rows:--task random-fly --no-cpu-baseline --schedule 65" "fly1024:--task random-fly --envs 1024 --no-cpu-baseline" "fly8192:--task random-fly --envs 8192 --no-cpu-baseline" "fly16384:--task random-fly --envs 16384 --no-cpu-baseline" "fly16384_lane:--task random-fly --envs 16384 --no-cpu-baseline --schedule 33" "fly65536:--task random-fly --envs 65536 --no-cpu-baseline --steps 300" "fly65536_lane:--task random-fly --envs 65536 --no-cpu-baseline --steps 300 --schedule 33"; do
+    name=${cfg%%:*}; args=${cfg#*:}
+    timeout -k 10 300 python bench.py $args > $O/bench_${TAG}_$name.json 2> $O/bench_${TAG}_$name.err || { echo "BENCH $name FAILED"; tail -5 $O/bench_${TAG}_$name.err; }
+    line $name $O/bench_${TAG}_$name.json
+  done
 else
   timeout -k 10 900 python tools/soak.py 4096 20000 > $O/soak_$TAG.txt 2>&1; cat $O/soak_$TAG.txt
   timeout -k 10 300 python tools/scripted_success.py 4096 > $O/scripted_success_$TAG.txt 2>&1; tail -2 $O/scripted_success_$TAG.txt

@@ -53,4 +53,8 @@ if __name__ == "__main__":
         for n in (1024, 4096, 16384):
             f = time_pre(n, 1, task); q = time_pre(n, 1 + 16, task); l = time_pre(n, 1 + 8, task)
             print("%s n=%5d: default (ONE fused launch%s) %.1f + %.1f us; controller / IK as a pre-launch, one env per QUAD %.1f + %.1f us; %s %.1f + %.1f us" % (
-                name, n, "; random-fly beyond 8192 envs: IK inside the step wavefront" if task else "", f[0], f[1], q[0], q[1], "IK inside the step wavefront" if task else "pre-launch, one env per LANE", l[0], l[1]))
+                name, n, "; random-fly: step wavefronts one env per quad of lanes, beyond 13 104 envs the IK inside them" if task else "", f[0], f[1], q[0], q[1],
+                "IK inside the step wavefront (quad layout)" if task else "pre-launch, one env per LANE", l[0], l[1]))
+            if task:
+                a = time_pre(n, 1 + 32, task); b = time_pre(n, 1 + 32 + 8, task)
+                print("%s n=%5d: step wavefronts one env per LANE (schedule + 32): fused (up to 8 192 envs) %.1f + %.1f us; IK inside %.1f + %.1f us" % (name, n, a[0], a[1], b[0], b[1]))
