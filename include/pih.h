@@ -102,8 +102,11 @@ typedef struct pih_config {
                                  +4: do not raise the issue priority of the wavefronts of contact-heavy envs (measurement switch);
                                  +8 / +16: the two-launch step of rounds 1-3 (controller launch, then physics launch) instead of the fused launch,
                                  with the controller / IK one env per LANE (+8) or one env per quad of lanes (+16) (measurement switches);
-                                 +32 (random-fly): one env per LANE in the step wavefronts at every batch size (default: one env per QUAD of
-                                 lanes up to 4 096 envs, 16 envs per wavefront, the PGS sweep split over the quad) */
+                                 +32 (random-fly): one env per LANE in the step wavefronts (default: one env per QUAD of lanes, 16 envs per
+                                 wavefront, the PGS sweep split over the quad; fused with the IK controller wavefronts while all workgroups
+                                 are resident together, n <= 13 104 on 256 CUs); +64 (random-fly): every joint-limit row in every sweep
+                                 (default: limit rows of joints farther than 0.25 rad from their limits are skipped and verified -- same
+                                 results bit for bit) (measurement switches) */
   int32_t enable_arm_collision; /* arm collision spheres (pih_model.h PIH_ARM_SPH_*): bit 0 vs the table plane, bit 1 vs the pipe (hand /
                                    flange / wrist spheres against the pipe's sample spheres); default 3 */
   int32_t task_id;            /* PIH_TASK_*: which task of TASK_LIST (envs/base_env.py:9-11) the handle simulates */
