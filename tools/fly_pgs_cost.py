@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from peg_in_hole_gym_amd.vec_env import PihVecEnv  # noqa: E402
 
 n = 1024
-for name, sched in (("quad, limit rows speculated", 1), ("quad, every limit row", 1 + 64), ("lane, speculated", 1 + 32), ("lane, every limit row", 1 + 32 + 64)):
+for name, sched in (("quad, residual form, limit rows speculated", 1), ("quad, residual form, every limit row", 1 + 64), ("quad, velocity form, speculated", 1 + 128), ("quad, velocity form, every limit row", 1 + 128 + 64), ("lane, speculated", 1 + 32), ("lane, every limit row", 1 + 32 + 64)):
     epw = 64 if sched & 32 else 16
     env = PihVecEnv(n, auto_reset=0, debug=2, task_id=1, dt=1 / 120.0, max_episode_steps=100000, contact_margin=0.02, residual_threshold=0.0, schedule=sched)
     s0 = env.state().clone()
@@ -32,4 +32,4 @@ for name, sched in (("quad, limit rows speculated", 1), ("quad, every limit row"
     d = env.debug().double().cpu()
     nc = d[:, 12].reshape(-1, epw).max(1).values; cyc = d[::epw, 905]
     rows = "; ".join("max contacts %d: %.0f" % (k, float(cyc[nc == k].mean()) / 50) for k in range(0, 6) if (nc == k).any())
-    print("%-30s joint rows alone: %.0f cycles per iteration (%.1f k per solve of 50); arm on the table, cycles per iteration by the wave's largest contact count: %s" % (name, out[-1] / 50, out[-1] / 1e3, rows))
+    print("%-42s joint rows alone: %.0f cycles per iteration (%.1f k per solve of 50); arm on the table, cycles per iteration by the wave's largest contact count: %s" % (name, out[-1] / 50, out[-1] / 1e3, rows))
