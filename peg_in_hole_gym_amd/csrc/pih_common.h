@@ -111,7 +111,7 @@ typedef real areal;
 
 struct Params {
   real dt, resid, erp, warm, margin, slop, ikdamp, ikres, dv;
-  int iters, ikiters, mode, maxsteps, autoreset, selfcol, armcol, debug, env0, pgsmode, attachball, noprio, nospec, noresid;
+  int iters, ikiters, mode, maxsteps, autoreset, selfcol, armcol, debug, env0, pgsmode, attachball, noprio, nospec;
   int object;        // random-fly: index of the free-flying object (pih_config.object_id)
   int checkstride;   // cadence of the PGS early-exit test (pih_config.exit_check_stride): 1 = every iteration (Bullet)
   uint64_t seed;

@@ -621,119 +621,8 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       }
       return worst;
     };
-    // The quad sweep in RESIDUAL form (the default of the quad layout; schedule + 128 keeps the velocity form above for A/B runs).  What a
-    // lone wavefront pays for is the chain of DEPENDENT instructions (~ 10 cycles each against 4 for an independent one,
-    // tools/fly_pgs_cost.py), and in the velocity form every row's chain runs through du: broadcast / dot product + quad all-reduce,
-    // clamp, difference, update -- 5 dependent instructions per joint, 9 per contact.  Here every row carries its own residual and a
-    // row's impulse change is pushed to the residuals of the rows still to come in this sweep by ONE multiply-add each, through
-    // precomputed couplings (Cq: joint to joint, M^-1[j][k] dinv[k]; Kd: contact to contact, dinv (J_c . W_c')): the chain is
-    // multiply-add, clamp, difference -- 3 per row.  du3 is still updated by every row (off the chain); the joints' residuals are
-    // refreshed from it at the start of a sweep (they see the contacts of the previous sweep that way), the contacts' residuals after
-    // the joints (one dot product + all-reduce per contact, all contacts at once: independent instructions).  Same row order, same
-    // clamps, same exit test; the sums are associated differently (tests: quad vs lane layout, quad vs oracle).
-    real gq[NJ], Cq[NJ][NJ], cjj[NJ], Kd[KR][KR], bq[KR];
-    if constexpr (Q::QUAD) {
-#pragma unroll
-      for (int j = 0; j < NJ; j++) {
-        cjj[j] = wjj[j] * mdi[j];
-#pragma unroll
-        for (int k = 0; k < NJ; k++) Cq[j][k] = Wm[j][k] * mdi[k];
-      }
-#pragma unroll
-      for (int c = 0; c < KR; c++) {
-#pragma unroll
-        for (int e = 0; e < KR; e++) Kd[c][e] = 0;
-        bq[c] = 0;
-      }
-#pragma unroll
-      for (int c = 1; c < KR; c++) {
-        if (c >= ncw) break;                 // (wave-uniform)
-#pragma unroll
-        for (int e = 0; e < c; e++) {
-          real kk = Rr[c][0] * Rr[e][3] + Rr[c][1] * Rr[e][4] + Rr[c][2] * Rr[e][5];
-          kk += quad.xor1(kk); kk += quad.xor2(kk);
-          Kd[c][e] = kk * Rr[c][6];
-        }
-      }
-    }
-    auto sweep_quad_r = [&](auto CHECKTAG) __attribute__((always_inline)) -> real {
-      constexpr bool CHECK = decltype(CHECKTAG)::value;
-      real worst = -1;
-      if constexpr (Q::QUAD) {
-        auto refresh = [&](auto JTAG) __attribute__((always_inline)) {
-          constexpr int j = decltype(JTAG)::value;
-          gq[j] = lam_m[j] + (mrhs[j] - quad.template bcast<(j / 3)>(du3[j % 3]) * mdi[j]);
-        };
-        refresh(std::integral_constant<int, 0>{}); refresh(std::integral_constant<int, 1>{}); refresh(std::integral_constant<int, 2>{});
-        refresh(std::integral_constant<int, 3>{}); refresh(std::integral_constant<int, 4>{}); refresh(std::integral_constant<int, 5>{});
-  #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-          const real lim = U_EFFORT[j] * dt, di = mdi[j];
-          const real sum = med3_(gq[j], -lim, lim), dl = sum - lam_m[j];
-          const real v1 = (lam_m[j] + mrhs[j] - gq[j]) + dl * cjj[j];       // dinv x (du[j] after the motor row)
-          lam_m[j] = sum;
-          if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
-          real tot = dl;
-          if (__builtin_expect(((limmask >> j) & 1) != 0, 0)) {        // (wave-uniform, out of line)
-            const real s2 = max_(lam_lo[j] + (lrl[j] - v1), (real)0), d2 = s2 - lam_lo[j];
-            lam_lo[j] = s2; tot += d2;
-            const real v2 = v1 + d2 * cjj[j];
-            const real s3 = max_(lam_hi[j] + (lrh[j] + v2), (real)0), d3 = s3 - lam_hi[j];
-            lam_hi[j] = s3; tot -= d3;
-            if (CHECK) { const real va = d2 * d2 - P.resid * di * di, vb = d3 * d3 - P.resid * di * di; worst = va > worst ? va : worst; worst = vb > worst ? vb : worst; }
-          } else {
-            viol = max_(viol, max_(lrl[j] - v1, lrh[j] + v1));          // the right-hand sides the skipped rows would have seen (exactly)
-          }
-  #pragma unroll
-          for (int k = j + 1; k < NJ; k++) gq[k] -= Cq[j][k] * tot;
-  #pragma unroll
-          for (int k = 0; k < 3; k++) du3[k] += Wq[j][k] * tot;
-        }
-        auto contacts = [&](auto NRTAG) __attribute__((always_inline)) {
-          constexpr int NR = decltype(NRTAG)::value;
-  #pragma unroll
-          for (int c = 0; c < NR; c++) {
-            real jd = Rr[c][0] * du3[0] + Rr[c][1] * du3[1] + Rr[c][2] * du3[2];
-            jd += quad.xor1(jd); jd += quad.xor2(jd);
-            bq[c] = lamr[c] + (Rr[c][7] - jd * Rr[c][6]);
-          }
-  #pragma unroll
-          for (int c = 0; c < NR; c++) {
-            if (c >= ncw) break;             // (wave-uniform: one taken branch per sweep)
-            const real sum = max_(bq[c], (real)0), dl = sum - lamr[c];
-            lamr[c] = sum;
-  #pragma unroll
-            for (int e = c + 1; e < NR; e++) bq[e] -= Kd[e][c] * dl;
-  #pragma unroll
-            for (int k = 0; k < 3; k++) du3[k] += Rr[c][3 + k] * dl;
-            if (CHECK) { const real di = Rr[c][6], v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
-          }
-        };
-        if (ncw > 4) contacts(std::integral_constant<int, KR>{});
-        else if (ncw > 0) contacts(std::integral_constant<int, 4>{});
-        // contacts KR .. (rare: a ninth contact of one env): velocity form, from lane memory
-        if (ncw > KR) {
-          for (int c = KR; c < nc; c++) {
-            real R[CWQ];
-  #pragma unroll
-            for (int i = 0; i < CWQ; i++) R[i] = mem.at(c * CWQ + i);
-            real jd = R[0] * du3[0] + R[1] * du3[1] + R[2] * du3[2];
-            jd += quad.xor1(jd); jd += quad.xor2(jd);
-            const real di = R[6], lam = R[8];
-            real dl = R[7] - jd * di;
-            const real sum = max_(lam + dl, (real)0);
-            dl = sum - lam; mem.at(c * CWQ + 8) = sum;
-  #pragma unroll
-            for (int k = 0; k < 3; k++) du3[k] += R[3 + k] * dl;
-            if (CHECK) { const real v = dl * dl - P.resid * di * di; worst = v > worst ? v : worst; }
-          }
-        }
-      }
-      return worst;
-    };
     auto one = [&](bool chk) __attribute__((always_inline)) -> bool {
       if constexpr (Q::QUAD) {
-        if (!P.noresid) return chk ? sweep_quad_r(std::true_type{}) <= 0 : (sweep_quad_r(std::false_type{}), false);
         return chk ? sweep_quad(std::true_type{}) <= 0 : (sweep_quad(std::false_type{}), false);
       }
       else return chk ? sweep(std::true_type{}) <= 0 : (sweep(std::false_type{}), false);
@@ -749,8 +638,8 @@ PIH_HD void step_env(real* S, const Params& P, int env_global, const real* actio
       }
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
-        const real a = lrl[j] * wjj[j], b = -lrh[j] * wjj[j];
         const bool full = ((limmask >> j) & 1) != 0;
+        const real a = lrl[j] * wjj[j], b = -lrh[j] * wjj[j];
         vlo[j] = full ? -(real)PIH_BIG : a + ((real)1e-5 * absr(a) + (real)1e-12);
         vhi[j] = full ? (real)PIH_BIG : b - ((real)1e-5 * absr(b) + (real)1e-12);
       }

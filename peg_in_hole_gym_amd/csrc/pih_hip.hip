@@ -563,7 +563,7 @@ static Params make_params(const pih_config* c) {
   P.dt = c->dt; P.resid = c->residual_threshold; P.erp = c->erp; P.warm = c->warmstart; P.margin = c->contact_margin;
   P.slop = c->linear_slop; P.ikdamp = c->ik_damping; P.ikres = c->ik_residual; P.dv = c->dv; P.iters = c->solver_iters;
   P.ikiters = c->ik_iters; P.mode = c->mode; P.maxsteps = c->max_episode_steps; P.autoreset = c->auto_reset;
-  P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball; P.noprio = (c->schedule & 4) != 0; P.nospec = (c->schedule & 64) != 0; P.noresid = (c->schedule & 128) != 0;
+  P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball; P.noprio = (c->schedule & 4) != 0; P.nospec = (c->schedule & 64) != 0;
   P.checkstride = c->exit_check_stride < 1 ? 1 : c->exit_check_stride;
   P.object = c->object_id;
   return P;

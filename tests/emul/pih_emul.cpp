@@ -26,7 +26,7 @@ static Params make_params(const pih_config* c) {
   P.dt = (real)c->dt; P.resid = (real)c->residual_threshold; P.erp = (real)c->erp; P.warm = (real)c->warmstart;
   P.margin = (real)c->contact_margin; P.slop = (real)c->linear_slop; P.ikdamp = (real)c->ik_damping; P.ikres = (real)c->ik_residual;
   P.dv = (real)c->dv; P.iters = c->solver_iters; P.ikiters = c->ik_iters; P.mode = c->mode; P.maxsteps = c->max_episode_steps;
-  P.autoreset = c->auto_reset; P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball; P.noprio = 1; P.nospec = (c->schedule & 64) != 0; P.noresid = (c->schedule & 128) != 0; P.checkstride = c->exit_check_stride < 1 ? 1 : c->exit_check_stride; P.object = c->object_id;
+  P.autoreset = c->auto_reset; P.selfcol = c->enable_self_collision; P.armcol = c->enable_arm_collision; P.debug = c->debug; P.env0 = c->env_index0; P.seed = c->seed; P.pgsmode = c->solver_path; P.attachball = c->attach_ball; P.noprio = 1; P.nospec = (c->schedule & 64) != 0; P.checkstride = c->exit_check_stride < 1 ? 1 : c->exit_check_stride; P.object = c->object_id;
   return P;
 }
 

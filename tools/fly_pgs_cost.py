@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from peg_in_hole_gym_amd.vec_env import PihVecEnv  # noqa: E402
 
 n = 1024
-for name, sched in (("quad, residual form, limit rows speculated", 1), ("quad, residual form, every limit row", 1 + 64), ("quad, velocity form, speculated", 1 + 128), ("quad, velocity form, every limit row", 1 + 128 + 64), ("lane, speculated", 1 + 32), ("lane, every limit row", 1 + 32 + 64)):
+for name, sched in (("quad, limit rows speculated", 1), ("quad, every limit row", 1 + 64), ("lane, speculated", 1 + 32), ("lane, every limit row", 1 + 32 + 64)):
     epw = 64 if sched & 32 else 16
     env = PihVecEnv(n, auto_reset=0, debug=2, task_id=1, dt=1 / 120.0, max_episode_steps=100000, contact_margin=0.02, residual_threshold=0.0, schedule=sched)
     s0 = env.state().clone()

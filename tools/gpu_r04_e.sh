@@ -8,7 +8,7 @@ tail -8 $O/gpu_tests_$TAG.log
 grep -n "quad vs lane\|many-contact" $O/gpu_tests_$TAG.log
 timeout -k 10 200 python tools/fly_trace.py 4096 > $O/fly_trace_$TAG.txt 2>&1; grep -A2 "launch 1" $O/fly_trace_$TAG.txt | cut -c1-700
 timeout -k 10 200 python tools/fly_pgs_cost.py > $O/fly_pgs_cost_$TAG.txt 2>&1; grep -v amdgpu.ids $O/fly_pgs_cost_$TAG.txt | cut -c1-330
-for cfg in "fly:--task random-fly --no-cpu-baseline" "fly_velocity_form:--task random-fly --no-cpu-baseline --schedule 129" "fly_lane:--task random-fly --no-cpu-baseline --schedule 33" "fly1024:--task random-fly --envs 1024 --no-cpu-baseline" "fly2048:--task random-fly --envs 2048 --no-cpu-baseline" "fly8192:--task random-fly --envs 8192 --no-cpu-baseline" "fly8192_lane:--task random-fly --envs 8192 --no-cpu-baseline --schedule 33" "fly12k:--task random-fly --envs 12288 --no-cpu-baseline" "fly16k:--task random-fly --envs 16384 --no-cpu-baseline" "fly16k_lane:--task random-fly --envs 16384 --no-cpu-baseline --schedule 33" "fly64k:--task random-fly --envs 65536 --no-cpu-baseline" "fly64k_lane:--task random-fly --envs 65536 --no-cpu-baseline --schedule 33"; do
+for cfg in "fly:--task random-fly --no-cpu-baseline" "fly_lane:--task random-fly --no-cpu-baseline --schedule 33" "fly1024:--task random-fly --envs 1024 --no-cpu-baseline" "fly2048:--task random-fly --envs 2048 --no-cpu-baseline" "fly8192:--task random-fly --envs 8192 --no-cpu-baseline" "fly8192_lane:--task random-fly --envs 8192 --no-cpu-baseline --schedule 33" "fly12k:--task random-fly --envs 12288 --no-cpu-baseline" "fly16k:--task random-fly --envs 16384 --no-cpu-baseline" "fly16k_lane:--task random-fly --envs 16384 --no-cpu-baseline --schedule 33" "fly64k:--task random-fly --envs 65536 --no-cpu-baseline" "fly64k_lane:--task random-fly --envs 65536 --no-cpu-baseline --schedule 33"; do
   name=${cfg%%:*}; args=${cfg#*:}
   timeout -k 10 300 python bench.py $args > $O/bench_${TAG}_$name.json 2> $O/bench_${TAG}_$name.err || { echo "BENCH $name FAILED"; tail -20 $O/bench_${TAG}_$name.err; exit 1; }
   python - <<PY
