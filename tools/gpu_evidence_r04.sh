@@ -65,4 +65,6 @@ elif [ "$PART" = "b" ]; then
 else
   timeout -k 10 900 python tools/soak.py 4096 20000 > $O/soak_$TAG.txt 2>&1; cat $O/soak_$TAG.txt
   timeout -k 10 300 python tools/scripted_success.py 4096 > $O/scripted_success_$TAG.txt 2>&1; tail -2 $O/scripted_success_$TAG.txt
+  timeout -k 10 600 python tools/soak.py 4096 50000 fly > $O/soak_fly_$TAG.txt 2>&1; cat $O/soak_fly_$TAG.txt
+  timeout -k 10 600 python tools/soak.py 12000 20000 fly > $O/soak_fly12000_$TAG.txt 2>&1; cat $O/soak_fly12000_$TAG.txt
 fi

@@ -15,7 +15,7 @@ cp $O/sq_$TAG.json $P/${TAG}_sq_counters.json;         cp $O/sq_$TAG.json $P/sq_
 cp $O/pmc_$TAG.json $P/${TAG}_pmc.json;                cp $O/pmc_$TAG.json $P/pmc_latest.json
 cp $O/sq_${TAG}_fly.json $P/${TAG}_fly_sq_counters.json; cp $O/sq_${TAG}_fly.json $P/sq_fly_latest.json
 cp $O/pmc_${TAG}_fly.json $P/${TAG}_fly_pmc.json;      cp $O/pmc_${TAG}_fly.json $P/pmc_fly_latest.json
-for n in env_cycles_1024 iter_cost sched_trace ik_bench fly_trace fly_trace_lane fly_pgs_cost soak scripted_success; do
+for n in env_cycles_1024 iter_cost sched_trace ik_bench fly_trace fly_trace_lane fly_pgs_cost soak soak_fly soak_fly12000 scripted_success; do
   [ -f $O/${n}_$TAG.txt ] && grep -v "amdgpu.ids" $O/${n}_$TAG.txt > $P/${TAG}_$n.txt
 done
 [ -f $O/r04_first_exceedance_test_N1024_of_4096.json ] && python $R/tools/merge_first_exceedance.py > /dev/null 2>&1 || true
