@@ -19,19 +19,19 @@ def test_parity_table_is_generated_from_the_committed_log(tmp_path):
 
 
 def _bench(name):
-    return json.loads(open(os.path.join(ROOT, "profiles", "bench_r04_v4_%s.json" % name)).read().strip().splitlines()[-1])
+    return json.loads(open(os.path.join(ROOT, "profiles", "bench_r04_v5_%s.json" % name)).read().strip().splitlines()[-1])
 
 
 def test_design_and_readme_quote_the_committed_numbers():
     design = open(os.path.join(ROOT, "DESIGN.md")).read(); readme = open(os.path.join(ROOT, "README.md")).read()
     for name in ("driver_shape", "default", "two_launch", "1024", "16384", "scripted", "exit_check_every_iteration", "fly"):
         v = "%.2f M" % (_bench(name)["value"] / 1e6)
-        assert v in design, "DESIGN.md does not quote %s of bench_r04_v4_%s.json" % (v, name)
+        assert v in design, "DESIGN.md does not quote %s of bench_r04_v5_%s.json" % (v, name)
     assert "%.2f M" % (_bench("driver_shape")["value"] / 1e6) in readme
     # the well-conditioned maximum of the defaults run: the figure round 3 misquoted
     log = open(os.path.join(ROOT, "profiles", "r04_gpu_tests.log")).read()
     m = re.search(r"HIP defaults N=4096 solver_path=0: \d+ env-steps; .*?max over the WELL-conditioned env-steps (\S+) ;", log)
     well = float(m.group(1))
     assert ("%.2e" % well).replace("e-0", "e-") in design
-    sq = json.load(open(os.path.join(ROOT, "profiles", "r04_v4_sq_counters.json")))
+    sq = json.load(open(os.path.join(ROOT, "profiles", "r04_v5_sq_counters.json")))
     assert "%.3f" % sq["launch_wide_valu_issue"] in design
