@@ -9,14 +9,14 @@ sched = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 for path in (0, 1):
     env = PihVecEnv(n, auto_reset=1, debug=2, solver_path=path, max_episode_steps=2227, schedule=sched)
     gen = torch.Generator(device="cuda").manual_seed(1234)
-    tot = []; pgs = []; cnt = []; smax = []; sarg = []; sph = []
+    tot = []; pgs = []; cnt = []; smax = []; sarg = []; sph = []; phs = []
     for t in range(460):
         env.step(torch.rand(n, 4, device="cuda", generator=gen) * 2 - 1)
         if t >= 400 and t % 5 == 0:
             d = env.debug()
-            tot.append(d[:, 900:908].sum(1)); pgs.append(d[:, 905]); cnt.append(env.state()[:, 106])
+            tot.append(d[:, 900:908].sum(1)); pgs.append(d[:, 905]); cnt.append(env.state()[:, 106]); phs.append(d[:, 900:908].clone())
             i = int(tot[-1].argmax()); smax.append(float(tot[-1][i])); sarg.append(int(cnt[-1][i])); sph.append(d[i, 900:908].tolist())
-    tot = torch.cat(tot); pgs = torch.cat(pgs); cnt = torch.cat(cnt)
+    tot = torch.cat(tot); pgs = torch.cat(pgs); cnt = torch.cat(cnt); phs = torch.cat(phs)
     q = lambda x, p: float(torch.quantile(x.float(), p))
     print("solver_path %d: per-env cycles mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f | PGS mean %.0f | mean contacts %.2f | sum/2048 slots %.0f" % (
         path, tot.mean(), q(tot, .5), q(tot, .9), q(tot, .99), tot.max(), pgs.mean(), cnt.mean(), tot.sum() / len(tot) * n / 2048))
@@ -27,4 +27,5 @@ for path in (0, 1):
     for lo, hi in ((0, 4), (5, 7), (8, 10), (11, 14), (15, 19), (20, 24), (25, 32), (33, 48)):
         m = (cnt >= lo) & (cnt <= hi)
         if m.any():
-            print("   contacts %2d..%2d: %5.1f %% of env-steps, total %.0f cycles, PGS %.0f" % (lo, hi, 100 * m.float().mean(), tot[m].mean(), pgs[m].mean()))
+            print("   contacts %2d..%2d: %5.1f %% of env-steps, total %.0f cycles, PGS %.0f; phases fk %.0f fsm %.0f collide %.0f aba %.0f rows %.0f pgs %.0f integrate %.0f fk2 %.0f" % (
+                (lo, hi, 100 * m.float().mean(), tot[m].mean(), pgs[m].mean()) + tuple(phs[m].mean(0).tolist())))
