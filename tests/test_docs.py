@@ -27,7 +27,7 @@ def test_design_and_readme_quote_the_committed_numbers():
     for name in ("driver_shape", "default", "two_launch", "1024", "16384", "scripted", "exit_check_every_iteration", "fly"):
         v = "%.2f M" % (_bench(name)["value"] / 1e6)
         assert v in design, "DESIGN.md does not quote %s of bench_r04_v5_%s.json" % (v, name)
-    assert "%.2f M" % (_bench("driver_shape")["value"] / 1e6) in readme
+    assert "%.2f M" % (_bench("driver_shape")["value"] / 1e6) in readme and "%.2f M" % (_bench("fly")["value"] / 1e6) in readme
     # the well-conditioned maximum of the defaults run: the figure round 3 misquoted
     log = open(os.path.join(ROOT, "profiles", "r04_gpu_tests.log")).read()
     m = re.search(r"HIP defaults N=4096 solver_path=0: \d+ env-steps; .*?max over the WELL-conditioned env-steps (\S+) ;", log)
