@@ -293,22 +293,22 @@ def test_roctx_ranges_do_not_disturb_the_step(torch_mod):
     assert torch.equal(a.state()[:, :128], b.state()[:, :128])
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_fused_launch_equals_the_two_launch_step(torch_mod, mode):
+@pytest.mark.parametrize("mode,n,steps", [(0, 2500, 150), (1, 2500, 150), (0, 16384, 40)])
+def test_fused_launch_equals_the_two_launch_step(torch_mod, mode, n, steps):
     """Round 4: one launch per step (controller wavefronts + env wavefronts in one grid, mailbox + release / acquire flag, dispatch order
     built in-kernel) against the two-launch step of rounds 1-3 with the same one-env-per-lane controller (pih_config.schedule + 8): the
     same arithmetic, so the states are bit-identical -- action mode with auto-reset and scripted mode (where the env waves read the
-    state-machine words from the mailbox before collision detection); odd batch size, several rounds of wavefronts; no controller time-out."""
+    state-machine words from the mailbox before collision detection); odd batch size, several rounds of wavefronts; no controller time-out.
+    16 384 envs: 16 640 workgroups per launch (the mailbox race of DESIGN section 6.0 needed hundreds of workgroups in flight to show)."""
     torch = torch_mod
-    n = 2500
     kw = dict(seed=3, auto_reset=1, max_episode_steps=90) if mode == 0 else dict(seed=3, mode=1, dv=0.05)
     a = _gpu(n, **kw); b = _gpu(n, schedule=1 + 8, **kw); c = _gpu(n, schedule=0, **kw)      # fused; two launches; fused without the dispatch order
     gen = torch.Generator(device="cuda").manual_seed(5)
-    for t in range(150):
+    for t in range(steps):
         act = torch.rand(n, 4, device="cuda", generator=gen) * 2 - 1
         oa = [x.clone() for x in a.step(act)]; ob = [x.clone() for x in b.step(act)]; oc = c.step(act)
         for x, y, z in zip(oa, ob, oc):
             assert torch.equal(x, y) and torch.equal(x, z), "step %d" % t
     assert torch.equal(a.state(), b.state()) and torch.equal(a.state(), c.state())
     a.set_timing(1); a.step(act); a.timing2()                 # timing2 also reports a controller time-out of the fused launch (-5): none
-    assert int(a.state()[:, 106].max().item()) > 10
+    assert int(a.state()[:, 106].max().item()) > (10 if steps >= 100 else 3)
