@@ -52,6 +52,19 @@ for rep in range(3):
             for e in lst:
                 t = heapq.heappop(h); worst = max(worst, t + durl[e]); heapq.heappush(h, t + durl[e])
         print("   greedy list scheduling of the measured durations (%s): makespan %.0f us; sum / 2048 = %.0f us" % (label, worst, sum(durl) / 2048))
+    # could ANOTHER order do better?  Longest-processing-time-first on the TRUE durations of this launch, and the best pairing when every
+    # slot gets two jobs (largest with smallest): the gap to sum / 2048 is the granularity of ~ 2 jobs per slot, not the order
+    def _sim(order):
+        h = [0.0] * 2048; heapq.heapify(h); worst = 0.0
+        for e in order:
+            t = heapq.heappop(h); worst = max(worst, t + durl[e]); heapq.heappush(h, t + durl[e])
+        return worst
+    srt = sorted(range(len(durl)), key=lambda e: -durl[e])
+    fold = [durl[e] for e in srt[:2048]]
+    for j, e in enumerate(srt[2048:]):
+        if j < 2048: fold[2047 - j] += durl[e]
+    print("   other orders, same durations: LPT on the true durations %.0f us; two jobs per slot, largest paired with smallest %.0f us; shortest first %.0f us" % (
+        _sim(srt), max(fold), _sim(srt[::-1])))
     te = torch.sort(t1).values
     for x in torch.unique(xcc)[:8]:
         m = xcc == x
